@@ -1,0 +1,675 @@
+// tafl_core.hpp — the rules engine as bit-parallel device functions (one game per lane).
+//
+// Re-expression (NOT a translation) of the reference's Tile-at-a-time logic:
+//   move generation   game/play.rs:139-226 + game/game/logic.rs:119-214  -> occluded Kogge-Stone ray fills
+//   captures          game/game/logic.rs:604-699                           -> shifted-mask custodial test
+//   shieldwall        game/game/logic.rs:471-569                           -> edge walk (rare, branchy)
+//   enclosure         game/game/logic.rs:309-401 (span fill)               -> bitboard flood to fixpoint
+//   enclosure_secure  game/game/logic.rs:408-463                           -> threat masks per axis
+//   exit fort         game/game/logic.rs:572-601
+//   outcome           game/game/logic.rs:702-771
+//   do_valid_play     game/game/logic.rs:782-820
+//   repetition        game/game/state.rs:41-114
+// Equality with the literal oracle (oracle/tafl_oracle.c) is checked by tests/test_hostsim_parity.py
+// (this header compiled for the host) and tests/test_gpu_parity.py (the HIP kernels).
+//
+// Rules are general over the reference `Ruleset` (game/rules.rs:83-117): all presets of
+// game/preset.rs run here, not only Copenhagen.
+#pragma once
+#include "tafl_bits.hpp"
+#include "../../include/taflhip.h"
+
+namespace tafl {
+
+enum : int { CLS_ATT = 0, CLS_DEF = 1, CLS_KING = 2 };
+enum : int { DIR_VP = 0, DIR_VM = 1, DIR_HP = 2, DIR_HM = 3 };
+
+// ---- constants derived on the host from (rules, side_len, word) ---------------------------------
+template <int NL>
+struct Consts {
+    Bits<NL> board, col0, coln, row0, rown, edge, corners, throne, throne_nb;
+    Bits<NL> land_forbid[3];     // tiles class c may not stop on (corners / throne by rule), logic.rs:190-206
+    Bits<NL> pass_forbid[3];     // empty tiles class c may not slide across,                  logic.rs:129-148,194-200
+    Bits<NL> hostile_special[3]; // special tiles hostile to class c (special_tile_hostile),   logic.rs:76-82
+    uint32_t n, w, throne_sq;
+    uint32_t slow[3], edge_hostile[3];
+    uint32_t king_like_soldier;  // king's movement masks equal the defender soldier's
+    tafl_rules rules;
+};
+
+// ---- per-game state in registers -------------------------------------------------------------------
+// flags: bit0 side(1=defender) bit1 attacker_mid_pair bit2 defender_mid_pair bits3-4 status
+//        bits5-8 reason bit9 winner(1=defender) bits16-19 king_row bits20-23 king_col
+template <int NL>
+struct DState {
+    Bits<NL> att, def;
+    uint32_t rep[4];   // oldest first; 0 = None; TAFL_REP_PACK layout
+    uint32_t turn, psc;
+    uint32_t reps;     // attacker_reps | defender_reps << 16
+    uint32_t flags;
+};
+#define TAFL_F_SIDE 0x1u
+#define TAFL_F_AMID 0x2u
+#define TAFL_F_DMID 0x4u
+#define TAFL_F_STATUS(f) (((f) >> 3) & 3u)
+#define TAFL_F_REASON(f) (((f) >> 5) & 15u)
+#define TAFL_F_WINNER(f) (((f) >> 9) & 1u)
+#define TAFL_F_KROW(f) (((f) >> 16) & 15u)
+#define TAFL_F_KCOL(f) (((f) >> 20) & 15u)
+#define TAFL_NO_SQ 0xFFFFu
+
+template <int NL>
+struct Moves {
+    Bits<NL> reach[4];   // destination sets per direction V+,V-,H+,H- (rays of distinct pieces are disjoint)
+    uint32_t cnt[4];
+    uint32_t total;
+};
+
+struct Move { uint32_t from, to, dir, dist; };
+
+template <int NL>
+struct StepOut {
+    Bits<NL> captures;
+    uint32_t n_captures;
+};
+
+template <int NL, int W>
+struct Engine {
+    using B = Bits<NL>;
+    using S = DState<NL>;
+    using K = Consts<NL>;
+
+    // ---- shifts along the four directions ----------------------------------------------------------
+    template <int DIR, int STEP> static TAFL_HD B shd(const B& a) {
+        if constexpr (DIR == DIR_VP) return shl<STEP * W>(a);
+        else if constexpr (DIR == DIR_VM) return shr<STEP * W>(a);
+        else if constexpr (DIR == DIR_HP) return shl<STEP>(a);
+        else return shr<STEP>(a);
+    }
+    // destinations that are NOT the product of a row wrap for a one-step move in DIR
+    template <int DIR> static TAFL_HD B nowrap(const K& C) {
+        if constexpr (DIR == DIR_HP) return andn(C.board, C.col0);
+        else if constexpr (DIR == DIR_HM) return andn(C.board, C.coln);
+        else return C.board;
+    }
+    // one step in DIR, on-board, no wrap
+    template <int DIR> static TAFL_HD B step1(const B& a, const K& C) { return shd<DIR, 1>(a) & nowrap<DIR>(C); }
+    static TAFL_HD B dilate(const B& a, const K& C) {
+        return step1<DIR_VP>(a, C) | step1<DIR_VM>(a, C) | step1<DIR_HP>(a, C) | step1<DIR_HM>(a, C);
+    }
+    // tiles whose neighbour in DIR is off the board
+    template <int DIR> static TAFL_HD B lastline(const K& C) {
+        if constexpr (DIR == DIR_VP) return C.rown; else if constexpr (DIR == DIR_VM) return C.row0;
+        else if constexpr (DIR == DIR_HP) return C.coln; else return C.col0;
+    }
+
+    static TAFL_HD uint32_t king_sq(const S& st, const K& C) {
+        const uint32_t r = TAFL_F_KROW(st.flags), c = TAFL_F_KCOL(st.flags);
+        return (r < C.n && c < C.n) ? r * (uint32_t)W + c : TAFL_NO_SQ;
+    }
+    // the tile that get_piece() reports as King: a defender standing on the nibble position
+    // (game/board/state.rs:173-187, :24-26)
+    static TAFL_HD B king_bit(const S& st, const K& C) {
+        const uint32_t k = king_sq(st, C);
+        return k == TAFL_NO_SQ ? bz<NL>() : (bit_at<NL>(k) & st.def);
+    }
+    static TAFL_HD bool king_armed_as_anvil(const K& C) { return C.rules.king_attack == TAFL_KING_ARMED || C.rules.king_attack == TAFL_KING_ANVIL; }
+
+    // ---- move generation: occluded ray fill (Kogge-Stone), replaces ValidPlayIterator -------------------
+    template <int DIR> static TAFL_HD B ray_reach(const B& gen0, const B& pass, const B& land, bool slow, const K& C) {
+        const B nw = nowrap<DIR>(C);
+        B g = gen0;
+        if (!slow) {
+            B p = pass & nw;
+            g |= p & shd<DIR, 1>(g); p &= shd<DIR, 1>(p);
+            g |= p & shd<DIR, 2>(g); p &= shd<DIR, 2>(p);
+            g |= p & shd<DIR, 4>(g);
+            if constexpr (W > 7) { p &= shd<DIR, 4>(p); g |= p & shd<DIR, 8>(g); }
+        }
+        return shd<DIR, 1>(g) & land & nw;
+    }
+    static TAFL_HD void class_reach(const B& gen, int cls, const B& empty, const K& C, B out[4]) {
+        const B pass = andn(empty, C.pass_forbid[cls]);
+        const B land = andn(empty, C.land_forbid[cls]);
+        const bool slow = C.slow[cls] != 0;
+        out[0] = ray_reach<DIR_VP>(gen, pass, land, slow, C);
+        out[1] = ray_reach<DIR_VM>(gen, pass, land, slow, C);
+        out[2] = ray_reach<DIR_HP>(gen, pass, land, slow, C);
+        out[3] = ray_reach<DIR_HM>(gen, pass, land, slow, C);
+    }
+    // get_all_possible_moves as destination sets (game/main.rs:33-43).  `side`: 0 attacker, 1 defender.
+    static TAFL_HD void movegen(const S& st, uint32_t side, const K& C, Moves<NL>& mv) {
+        TAFL_UNROLL for (int d = 0; d < 4; ++d) { mv.reach[d] = bz<NL>(); mv.cnt[d] = 0; }
+        mv.total = 0;
+        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return;         // logic.rs:165-167
+        const B occ = st.att | st.def;
+        const B empty = andn(C.board, occ);
+        if (side == 0) {
+            class_reach(st.att & C.board, CLS_ATT, empty, C, mv.reach);
+        } else {
+            const B kb = king_bit(st, C);
+            if (C.king_like_soldier) {
+                class_reach(st.def & C.board, CLS_DEF, empty, C, mv.reach);
+            } else {
+                class_reach(andn(st.def & C.board, kb), CLS_DEF, empty, C, mv.reach);
+                if (any(kb)) {
+                    B kr[4];
+                    class_reach(kb, CLS_KING, empty, C, kr);
+                    TAFL_UNROLL for (int d = 0; d < 4; ++d) mv.reach[d] |= kr[d];
+                }
+            }
+        }
+        TAFL_UNROLL for (int d = 0; d < 4; ++d) { mv.cnt[d] = popc(mv.reach[d]); mv.total += mv.cnt[d]; }
+    }
+
+    static TAFL_HD int delta(uint32_t dir) { return dir == 0 ? W : dir == 1 ? -W : dir == 2 ? 1 : -1; }
+
+    // the piece that reaches `to` moving in `dir`: nearest occupied tile behind `to`
+    static TAFL_HD Move resolve(const S& st, uint32_t dir, uint32_t to) {
+        const B occ = st.att | st.def;
+        const int dl = delta(dir);
+        int sq = (int)to; uint32_t dist = 0;
+        do { sq -= dl; ++dist; } while (dist < 32 && !test(occ, (uint32_t)sq));
+        Move m; m.from = (uint32_t)sq; m.to = to; m.dir = dir; m.dist = dist;
+        return m;
+    }
+    // idx-th play in ROLLOUT ORDER = (direction, destination tile ascending)  [build-defined, DESIGN.md]
+    static TAFL_HD Move pick_rollout(const S& st, const Moves<NL>& mv, uint32_t idx) {
+        uint32_t dir = 0; B r = mv.reach[0];
+        if (idx >= mv.cnt[0]) { idx -= mv.cnt[0]; dir = 1; r = mv.reach[1];
+            if (idx >= mv.cnt[1]) { idx -= mv.cnt[1]; dir = 2; r = mv.reach[2];
+                if (idx >= mv.cnt[2]) { idx -= mv.cnt[2]; dir = 3; r = mv.reach[3]; } } }
+        return resolve(st, dir, nth_set_bit(r, idx));
+    }
+
+    // ---- canonical iteration (ValidPlayIterator order: play.rs:157,166-183 over iter_occupied) -------------
+    // piece class of an occupied tile of `side`
+    static TAFL_HD int cls_of(const S& st, uint32_t side, uint32_t sq, const K& C) {
+        if (side == 0) return CLS_ATT;
+        return (sq == king_sq(st, C)) ? CLS_KING : CLS_DEF;
+    }
+    // Next legal play after `cur` in canonical order (cur = canon_start() to begin).  Returns false when the
+    // side has no further play.  Literal stepping of ValidPlayIterator::next (play.rs:189-225): used once per
+    // simulation (tree expansion) and by the dense-mask writer, never per rollout ply.
+    static TAFL_HD bool canon_next(const S& st, uint32_t side, const K& C, Move& cur) {
+        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return false;
+        const B occ = st.att | st.def;
+        const B mine = (side == 0 ? st.att : st.def) & C.board;
+        uint32_t sq = cur.from, dir = cur.dir, dist = cur.dist;
+        if (sq == TAFL_NO_SQ) {                       // start: first piece of the side (iter_occupied order)
+            if (!any(mine)) return false;
+            sq = lsb(mine); dir = 0; dist = 0;
+        }
+        for (;;) {
+            const int cls = cls_of(st, side, sq, C);
+            const int r0 = (int)(sq / (uint32_t)W), c0 = (int)(sq % (uint32_t)W);
+            if (dist > 0) {
+                // resuming after a yield: a landable tile that cannot be passed (NoPass/KingPass throne) ends the ray
+                const int dl = delta(dir);
+                const uint32_t xp = (uint32_t)((int)sq + dl * (int)dist);
+                if (test(C.pass_forbid[cls], xp)) { ++dir; dist = 0; }
+            }
+            while (dir < 4) {
+                const uint32_t nd = dist + 1;
+                int rr = r0, cc = c0;
+                if (dir == 0) rr += (int)nd; else if (dir == 1) rr -= (int)nd; else if (dir == 2) cc += (int)nd; else cc -= (int)nd;
+                bool end_dir = (rr < 0 || cc < 0 || rr >= (int)C.n || cc >= (int)C.n);          // off board
+                uint32_t x = 0;
+                if (!end_dir) {
+                    x = (uint32_t)rr * (uint32_t)W + (uint32_t)cc;
+                    if (test(occ, x)) end_dir = true;                                         // BlockedByPiece
+                    else if (C.slow[cls] && nd > 1) end_dir = true;                           // TooFar (never yields)
+                }
+                if (!end_dir) {
+                    if (!test(C.land_forbid[cls], x)) {
+                        cur.from = sq; cur.to = x; cur.dir = dir; cur.dist = nd;
+                        return true;
+                    }
+                    if (test(C.pass_forbid[cls], x)) end_dir = true;                          // neither occupy nor pass
+                    else { dist = nd; continue; }                                             // pass (empty throne)
+                }
+                ++dir; dist = 0;
+            }
+            // all four directions exhausted: next piece in ascending bit order
+            if (sq + 1 >= (uint32_t)(NL * 32)) return false;
+            const B rest = andn(mine, below<NL>(sq + 1));
+            if (!any(rest)) return false;
+            sq = lsb(rest); dir = 0; dist = 0;
+        }
+    }
+    static TAFL_HD Move canon_start() { Move m; m.from = TAFL_NO_SQ; m.to = 0; m.dir = 0; m.dist = 0; return m; }
+
+    // ---- validate_play_for_side (logic.rs:159-214) --------------------------------------------------------
+    static TAFL_HD int validate(const S& st, tafl_play p, uint32_t side, const K& C, Move* out) {
+        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return TAFL_PLAY_GAME_OVER;
+        const uint32_t fr = p.from_row, fc = p.from_col;
+        const bool from_in = fr < C.n && fc < C.n;
+        // get_piece(from) masks bit row*ROW_WIDTH+col of the raw reference words with no bounds check
+        // (bitfield.rs:72-74, board/state.rs:173-187): an off-board `from` can alias another tile, or the king nibble
+        // in the top four bits.  Reproduced so that the error code matches the reference for ANY play.
+        const uint32_t from = fr * (uint32_t)W + fc;
+        const B occ = st.att | st.def;
+        auto raw_test = [&](const B& word, uint32_t nib, uint32_t idx) -> bool {
+            if (idx >= (uint32_t)(NL * 32)) return false;
+            if (idx >= (uint32_t)(NL * 32 - 4)) return (nib >> (idx - (uint32_t)(NL * 32 - 4))) & 1u;
+            return test(word, idx);
+        };
+        const bool has_def = raw_test(st.def, TAFL_F_KROW(st.flags), from), has_att = raw_test(st.att, TAFL_F_KCOL(st.flags), from);
+        if (!has_def && !has_att) return TAFL_PLAY_NO_PIECE;
+        const uint32_t pside = has_def ? 1u : 0u;
+        if (pside != side) return TAFL_PLAY_WRONG_PLAYER;
+        int tr = (int)fr, tc = (int)fc;
+        const bool horiz = p.axis != 0;
+        if (horiz) tc += p.disp; else tr += p.disp;
+        tr &= 0xFF; tc &= 0xFF;                                                    // Play::to casts to u8 (play.rs:59-62)
+        if (!(from_in && (uint32_t)tr < C.n && (uint32_t)tc < C.n)) return TAFL_PLAY_OUT_OF_BOUNDS;
+        // NoCommonAxis cannot arise from (axis, displacement) plays
+        const uint32_t to = (uint32_t)tr * (uint32_t)W + (uint32_t)tc;
+        if (test(occ, to)) return TAFL_PLAY_BLOCKED_BY_PIECE;
+        const int cls = has_def ? ((fr == TAFL_F_KROW(st.flags) && fc == TAFL_F_KCOL(st.flags)) ? CLS_KING : CLS_DEF) : CLS_ATT;
+        const int dl = horiz ? 1 : W;
+        const uint32_t lo = from < to ? from : to, hi = from < to ? to : from;
+        bool through_throne = false;
+        for (uint32_t x = lo + (uint32_t)dl; x < hi; x += (uint32_t)dl) {
+            if (test(occ, x)) return TAFL_PLAY_BLOCKED_BY_PIECE;
+            if (x == C.throne_sq) through_throne = true;
+        }
+        if (test(C.corners, to) && !((C.rules.may_enter_corners >> (cls == CLS_ATT ? 1 : cls == CLS_DEF ? 9 : 8)) & 1u))
+            return TAFL_PLAY_MOVE_ONTO_BLOCKED_TILE;
+        const bool is_king = cls == CLS_KING;
+        if ((C.rules.throne_movement == TAFL_THRONE_NOPASS || (C.rules.throne_movement == TAFL_THRONE_KINGPASS && !is_king)) && through_throne)
+            return TAFL_PLAY_MOVE_THROUGH_BLOCKED_TILE;
+        if ((C.rules.throne_movement == TAFL_THRONE_NOENTRY || (C.rules.throne_movement == TAFL_THRONE_KINGENTRY && !is_king)) && to == C.throne_sq)
+            return TAFL_PLAY_MOVE_ONTO_BLOCKED_TILE;
+        const uint32_t dist = (uint32_t)(p.disp < 0 ? -(int)p.disp : (int)p.disp);
+        if (C.slow[cls] && dist > 1) return TAFL_PLAY_TOO_FAR;
+        if (out) { out->from = from; out->to = to; out->dist = dist; out->dir = horiz ? (p.disp > 0 ? 2u : 3u) : (p.disp > 0 ? 0u : 1u); }
+        return TAFL_PLAY_OK;
+    }
+
+    // ---- enclosure: bitboard flood (replaces the span fill of logic.rs:309-401) -----------------------------
+    // inside: tiles that can be filled (empty + enclosed piece types); neither: pieces that abort the search.
+    // Returns false for `None`.  fill = occupied ∪ unoccupied; boundary = enclosing pieces adjacent to the fill.
+    static TAFL_HD bool flood(uint32_t start_sq, const B& inside, const B& neither, bool abort_edge, bool abort_corner,
+                              const K& C, B& fill) {
+        if (start_sq == TAFL_NO_SQ) return false;
+        B f = bit_at<NL>(start_sq) & inside;
+        if (!any(f)) return false;
+        B stopmask = bz<NL>();
+        if (abort_edge) stopmask |= C.edge;
+        if (abort_corner) stopmask |= C.corners;
+        for (int it = 0; it < NL * 32; ++it) {
+            if (any(f & stopmask)) return false;
+            const B d = dilate(f, C);
+            if (any(d & neither)) return false;
+            const B nf = f | (d & inside);
+            if (eq(nf, f)) break;
+            f = nf;
+        }
+        fill = f;
+        return true;
+    }
+
+    // enclosure_secure (logic.rs:408-463) for a boundary made of soldiers of class `bcls`
+    static TAFL_HD bool secure(const S& st, const B& fill, const B& boundary, int bcls, bool inside_safe, bool outside_safe, const K& C) {
+        if (inside_safe && outside_safe) return true;
+        const B occ = st.att | st.def;
+        const B empty = andn(C.board, occ);
+        const int hcls = bcls == CLS_ATT ? CLS_DEF : CLS_ATT;                       // hostile soldier
+        B enemy = bcls == CLS_ATT ? st.def : st.att;
+        if (bcls == CLS_ATT && !king_armed_as_anvil(C)) enemy = andn(enemy, king_bit(st, C));
+        const B th = (enemy & C.board) | (empty & C.hostile_special[bcls]);         // tile_hostile
+        B safe = bz<NL>();
+        if (inside_safe) safe |= fill;
+        if (outside_safe) safe |= andn(C.board, fill);
+        const B a = andn(safe, C.hostile_special[bcls]);
+        const B b = andn(occ | C.land_forbid[hcls], th);
+        const B thr = andn(C.board, a | b);                                         // threatening tiles
+        const bool eh = C.edge_hostile[bcls] != 0;
+        const B up = step1<DIR_VP>(thr, C) | gate(C.row0, eh);     // tile above is threatening
+        const B dn = step1<DIR_VM>(thr, C) | gate(C.rown, eh);
+        const B lf = step1<DIR_HP>(thr, C) | gate(C.col0, eh);
+        const B rt = step1<DIR_HM>(thr, C) | gate(C.coln, eh);
+        return !any(boundary & ((up & dn) | (lf & rt)));
+    }
+
+    // detect_exit_fort (logic.rs:572-601)
+    static TAFL_HD bool exit_fort(const S& st, const K& C) {
+        const uint32_t k = king_sq(st, C);
+        if (k == TAFL_NO_SQ) return false;
+        const B kt = bit_at<NL>(k);
+        if (!any(kt & C.edge)) return false;
+        const B occ = st.att | st.def;
+        const B empty = andn(C.board, occ);
+        const B inside = empty | (kt & st.def);
+        B fill;
+        if (!flood(k, inside, st.att & C.board, false, true, C, fill)) return false;
+        if (!any(dilate(kt, C) & empty)) return false;
+        const B boundary = dilate(fill, C) & andn(st.def, fill);
+        return secure(st, fill, boundary, CLS_DEF, true, false, C);
+    }
+
+    // ---- shieldwall (logic.rs:471-569): literal walk along the edge, rare --------------------------------------
+    static TAFL_HD bool sw_search(const S& st, uint32_t to, bool horiz, int away, int dir, uint32_t mover, const K& C, B& wall) {
+        const B occ = st.att | st.def;
+        const B mine = mover ? st.def : st.att, theirs = mover ? st.att : st.def;
+        int r = (int)(to / (uint32_t)W), c = (int)(to % (uint32_t)W);
+        wall = bz<NL>(); uint32_t n_wall = 0;
+        for (int guard = 0; guard < 32; ++guard) {
+            if (horiz) c += dir; else r += dir;
+            if (r < 0 || c < 0 || r >= (int)C.n || c >= (int)C.n) return false;
+            const uint32_t t = (uint32_t)r * (uint32_t)W + (uint32_t)c;
+            const bool occd = test(occ, t), corner = test(C.corners, t);
+            if (!(occd || (C.rules.sw_corners_may_close && corner))) return false;
+            if (!occd) return n_wall >= 2;
+            if (test(theirs, t)) {
+                const int pr = horiz ? r + away : r, pc = horiz ? c : c + away;
+                if (pr < 0 || pc < 0 || pr >= (int)C.n || pc >= (int)C.n) return false;
+                const uint32_t pin = (uint32_t)pr * (uint32_t)W + (uint32_t)pc;
+                if (test(mine, pin)) { wall |= bit_at<NL>(t); ++n_wall; } else return false;
+            }
+            if (test(mine, t) || (corner && C.rules.sw_corners_may_close)) return n_wall >= 2;
+        }
+        return false;
+    }
+    static TAFL_HD B shieldwall(const S& st, uint32_t to, uint32_t mover, const K& C) {
+        if (!C.rules.has_shieldwall) return bz<NL>();
+        const uint32_t r = to / (uint32_t)W, c = to % (uint32_t)W;
+        bool horiz; int away;
+        if (r == 0) { horiz = true; away = 1; } else if (r == C.n - 1) { horiz = true; away = -1; }
+        else if (c == 0) { horiz = false; away = 1; } else if (c == C.n - 1) { horiz = false; away = -1; }
+        else return bz<NL>();
+        B wall;
+        bool found = sw_search(st, to, horiz, away, -1, mover, C, wall);
+        if (!found) found = sw_search(st, to, horiz, away, 1, mover, C, wall);
+        if (!found) return bz<NL>();
+        // filter by sw_rule.captures (logic.rs:562-565); wall tiles hold pieces of the non-moving side
+        const B kb = king_bit(st, C);
+        const uint32_t sold_bit = mover ? 1u : 9u, king_bitpos = 8u;
+        B keep = bz<NL>();
+        if ((C.rules.sw_captures >> sold_bit) & 1u) keep |= andn(wall, kb);
+        if ((C.rules.sw_captures >> king_bitpos) & 1u) keep |= wall & kb;
+        return keep;
+    }
+
+    // ---- get_captures (logic.rs:604-699) on the post-move board, side_to_play still the mover ------------------
+    template <int DIR> static TAFL_HD B custodial_dir(const B& tbit, const B& victims, const B& hostile, bool edge_h, const K& C) {
+        constexpr int OPP = DIR ^ 1;
+        const B nb = step1<DIR>(tbit, C);
+        const B far_h = step1<OPP>(hostile, C) | gate(lastline<DIR>(C), edge_h);
+        return nb & victims & far_h;
+    }
+    static TAFL_HD B captures(const S& st, const Move& m, uint32_t mover, bool mover_is_king, const K& C) {
+        B caps = bz<NL>();
+        const B tbit = bit_at<NL>(m.to);
+        const B occ = st.att | st.def;
+        const B empty = andn(C.board, occ);
+        const B kb = king_bit(st, C);
+        if (!mover_is_king || C.rules.king_attack == TAFL_KING_ARMED || C.rules.king_attack == TAFL_KING_HAMMER) {
+            // hostile-to-victim occupied tiles: mover-side pieces, an unarmed king excluded (tile_hostile :85-93)
+            B friends = (mover ? st.def : st.att) & C.board;
+            if (mover && !king_armed_as_anvil(C)) friends = andn(friends, kb);
+            const int vcls = mover ? CLS_ATT : CLS_DEF;
+            const B victims = mover ? (st.att & C.board) : andn(st.def & C.board, kb);   // enemy soldiers
+            const B hostile = friends | (empty & C.hostile_special[vcls]);
+            const bool eh = C.edge_hostile[vcls] != 0;
+            B cs = custodial_dir<DIR_VP>(tbit, victims, hostile, eh, C) | custodial_dir<DIR_VM>(tbit, victims, hostile, eh, C)
+                 | custodial_dir<DIR_HP>(tbit, victims, hostile, eh, C) | custodial_dir<DIR_HM>(tbit, victims, hostile, eh, C);
+            // Linnaean capture (logic.rs:676-685, :859-879): only for victims whose far tile was not hostile
+            if (C.rules.linnaean_capture && mover == 0 && any(kb & C.throne)) {
+                const B hk = (st.att & C.board) | (empty & C.hostile_special[CLS_KING]);
+                if (popc(C.throne_nb & hk) == 3) {
+                    // victim n adjacent to `to` with far == throne: n is a throne neighbour in line with `to`
+                    B lin = (step1<DIR_VP>(tbit, C) & step1<DIR_VM>(C.throne, C)) | (step1<DIR_VM>(tbit, C) & step1<DIR_VP>(C.throne, C))
+                          | (step1<DIR_HP>(tbit, C) & step1<DIR_HM>(C.throne, C)) | (step1<DIR_HM>(tbit, C) & step1<DIR_HP>(C.throne, C));
+                    cs |= lin & victims;
+                }
+            }
+            caps |= cs;
+            // enemy king next to the destination (only an attacker can face it)
+            if (mover == 0 && any(dilate(tbit, C) & kb)) {
+                const uint32_t k = king_sq(st, C);
+                const B hk = (st.att & C.board) | (empty & C.hostile_special[CLS_KING]);   // tile_hostile(·, king)
+                const bool ehk = C.edge_hostile[CLS_KING] != 0;
+                const bool beside = any(kb & C.throne_nb);
+                bool captured = false;
+                // (i) strong-by-throne king beside his throne, every neighbour hostile or the throne (logic.rs:621-632)
+                if (beside && C.rules.king_strength == TAFL_KING_STRONG_BY_THRONE
+                    && (C.rules.throne_movement == TAFL_THRONE_NOENTRY || C.rules.throne_movement == TAFL_THRONE_KINGENTRY)) {
+                    const B nbk = dilate(kb, C);
+                    if (!any(andn(andn(nbk, C.throne), hk))) captured = true;
+                }
+                if (!captured) {
+                    // (ii) far tile hostile (logic.rs:634-675)
+                    const int kr = (int)(k / (uint32_t)W), kc = (int)(k % (uint32_t)W);
+                    const int tr = (int)(m.to / (uint32_t)W), tc = (int)(m.to % (uint32_t)W);
+                    const int fr = tr + (kr - tr) * 2, fc = tc + (kc - tc) * 2;
+                    auto host = [&](int r, int c) -> bool {
+                        if (r < 0 || c < 0 || r >= (int)C.n || c >= (int)C.n) return ehk;
+                        return test(hk, (uint32_t)r * (uint32_t)W + (uint32_t)c);
+                    };
+                    if (host(fr, fc)) {
+                        bool strong;
+                        switch (C.rules.king_strength) {
+                            case TAFL_KING_STRONG: strong = true; break;
+                            case TAFL_KING_WEAK: strong = false; break;
+                            default: strong = beside || any(kb & C.throne); break;
+                        }
+                        if (strong) {
+                            const bool perp = (tr == kr) ? (host(kr + 1, kc) && host(kr - 1, kc)) : (host(kr, kc + 1) && host(kr, kc - 1));
+                            captured = perp;
+                        } else captured = true;
+                    }
+                }
+                if (captured) caps |= kb;
+            }
+        }
+        if (any(tbit & C.edge)) caps |= shieldwall(st, m.to, mover, C);
+        return caps;
+    }
+
+    // ---- RepetitionTracker::track_play (game/game/state.rs:92-113) ------------------------------------------------
+    static TAFL_HD void track(S& st, uint32_t mover, const Move& m, bool captured) {
+        const uint32_t fr = m.from / (uint32_t)W, fc = m.from % (uint32_t)W;
+        const bool horiz = m.dir >= 2; const int disp = (m.dir & 1) ? -(int)m.dist : (int)m.dist;
+        const uint32_t rec = TAFL_REP_PACK(mover, fr, fc, horiz, disp, captured);
+        uint32_t ar = st.reps & 0xFFFFu, dr = st.reps >> 16;
+        if (!captured && rec == st.rep[0]) {
+            const uint32_t midbit = mover ? TAFL_F_DMID : TAFL_F_AMID;
+            const bool is_rep = !(st.flags & midbit);
+            st.flags ^= midbit;
+            if (is_rep) { if (mover) dr = dr < 0xFFFFu ? dr + 1 : dr; else ar = ar < 0xFFFFu ? ar + 1 : ar; }
+        } else {
+            if (mover) { dr = 0; st.flags &= ~TAFL_F_DMID; } else { ar = 0; st.flags &= ~TAFL_F_AMID; }
+        }
+        st.reps = ar | (dr << 16);
+        st.rep[0] = st.rep[1]; st.rep[1] = st.rep[2]; st.rep[2] = st.rep[3]; st.rep[3] = rec;
+    }
+
+    // ---- do_valid_play (logic.rs:782-820) + get_game_outcome (:702-771) ---------------------------------------------
+    // `next` receives the opponent's move set (computed for the NoPlays test, reused by rollouts).
+    static TAFL_HD void apply(S& st, const Move& m, const K& C, StepOut<NL>* out, Moves<NL>& next) {
+        const uint32_t mover = st.flags & TAFL_F_SIDE;
+        const B fbit = bit_at<NL>(m.from), tbit = bit_at<NL>(m.to);
+        const bool mover_is_king = mover && m.from == king_sq(st, C);
+        // board.move_piece (board/state.rs:218-223)
+        if (mover) {
+            st.def = andn(st.def, fbit) | tbit; st.att = andn(st.att, tbit);
+            if (mover_is_king) {
+                const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W;
+                st.flags = (st.flags & ~0x00FF0000u) | (r << 16) | (c << 20);
+            }
+        } else { st.att = andn(st.att, fbit) | tbit; st.def = andn(st.def, tbit); }
+        const B caps = captures(st, m, mover, mover_is_king, C);
+        const bool king_captured_tile = mover == 0 && king_sq(st, C) != TAFL_NO_SQ && test(caps, king_sq(st, C));
+        st.att = andn(st.att, caps); st.def = andn(st.def, caps);
+        const uint32_t ncap = popc(caps);
+        if (out) { out->captures = caps; out->n_captures = ncap; }
+        track(st, mover, m, ncap != 0);
+        if (ncap == 0) st.psc += 1;
+        // outcome
+        uint32_t status = TAFL_STATUS_ONGOING, reason = 0, winner = 0;
+        const B other = (mover ? st.att : st.def) & C.board;
+        bool over = false;
+        if (!any(other)) { status = TAFL_STATUS_WIN; reason = TAFL_WIN_ALL_CAPTURED; winner = mover; over = true; }
+        if (!over && mover == 0) {
+            if (king_captured_tile) { status = TAFL_STATUS_WIN; reason = TAFL_WIN_KING_CAPTURED; winner = 0; over = true; }
+            else if (C.rules.enclosure_win != TAFL_ENCL_NONE) {
+                B fill;
+                const B inside = andn(C.board, st.att);
+                if (flood(king_sq(st, C), inside, bz<NL>(), C.rules.enclosure_win == TAFL_ENCL_WITHOUT_EDGE_ACCESS, true, C, fill)) {
+                    if (popc(fill & st.def) == popc(st.def & C.board)) {
+                        const B boundary = dilate(fill, C) & st.att;
+                        if (secure(st, fill, boundary, CLS_ATT, false, true, C)) {
+                            status = TAFL_STATUS_WIN; reason = TAFL_WIN_ENCLOSED; winner = 0; over = true;
+                        }
+                    }
+                }
+            }
+        } else if (!over) {
+            if (mover_is_king && any(tbit & (C.rules.edge_escape ? C.edge : C.corners))) {
+                status = TAFL_STATUS_WIN; reason = TAFL_WIN_KING_ESCAPED; winner = 1; over = true;
+            } else if (C.rules.exit_fort && exit_fort(st, C)) {
+                status = TAFL_STATUS_WIN; reason = TAFL_WIN_EXIT_FORT; winner = 1; over = true;
+            }
+        }
+        if (!over && C.rules.has_repetition_rule) {
+            const uint32_t reps = mover ? (st.reps >> 16) : (st.reps & 0xFFFFu);
+            if (reps >= C.rules.n_repetitions) {
+                if (C.rules.rep_is_loss) { status = TAFL_STATUS_WIN; reason = TAFL_WIN_REPETITION; winner = mover ^ 1u; }
+                else { status = TAFL_STATUS_DRAW; reason = TAFL_DRAW_REPETITION; }
+                over = true;
+            }
+        }
+        // side_can_play(other) (logic.rs:760-768, :837-846): status is still Ongoing while it is evaluated
+        if (!over) {
+            movegen(st, mover ^ 1u, C, next);
+            if (next.total == 0) {
+                if (C.rules.draw_on_no_plays) { status = TAFL_STATUS_DRAW; reason = TAFL_DRAW_NO_PLAYS; }
+                else { status = TAFL_STATUS_WIN; reason = TAFL_WIN_NO_PLAYS; winner = mover; }
+                over = true;
+            }
+        }
+        if (over) { TAFL_UNROLL for (int d = 0; d < 4; ++d) { next.reach[d] = bz<NL>(); next.cnt[d] = 0; } next.total = 0; }
+        st.turn += 1;
+        st.flags = (st.flags & ~(TAFL_F_SIDE | (0x7Fu << 3))) | (mover ^ 1u) | (status << 3) | (reason << 5) | (winner << 9);
+    }
+
+    // ---- taflmix32 RNG (build-defined) -----------------------------------------------------------------------
+    static TAFL_HD uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
+    static TAFL_HD uint32_t game_key(uint64_t seed, uint64_t game_id) {
+        const uint32_t h0 = fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) + 0x9E3779B9u));
+        return fmix32(fmix32(h0 ^ (uint32_t)game_id) + (uint32_t)(game_id >> 32));
+    }
+    static TAFL_HD uint32_t sim_key(uint32_t gk, uint32_t sim) { return fmix32(gk ^ (sim * 0x9E3779B1u + 0x7F4A7C15u)); }
+    static TAFL_HD uint32_t ply_rand(uint32_t sk, uint32_t ply) { return fmix32(sk + ply * 0x85EBCA77u); }
+    static TAFL_HD uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+    // one seeded uniform-random playout, state modified in place.  value for `start_side`.
+    static TAFL_HD void rollout(S& st, uint32_t sk, uint32_t max_plies, const K& C, tafl_rollout_result& res) {
+        const uint32_t start_side = st.flags & TAFL_F_SIDE;
+        Moves<NL> mv;
+        movegen(st, start_side, C, mv);
+        uint32_t ply = 0; bool stuck = false;
+        while (ply < max_plies && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
+            if (mv.total == 0) { stuck = true; break; }
+            const uint32_t idx = mulhi(ply_rand(sk, ply), mv.total);
+            const Move m = pick_rollout(st, mv, idx);
+            Moves<NL> nx;
+            apply(st, m, C, nullptr, nx);
+            mv = nx;
+            ++ply;
+        }
+        finish_rollout(st, start_side, ply, stuck, res);
+    }
+    static TAFL_HD void finish_rollout(const S& st, uint32_t start_side, uint32_t ply, bool stuck, tafl_rollout_result& res) {
+        const uint32_t status = TAFL_F_STATUS(st.flags);
+        res.plies = ply; res.status = (uint8_t)status; res.winner = (uint8_t)(TAFL_F_WINNER(st.flags) ? TAFL_DEFENDER : TAFL_ATTACKER);
+        if (status == TAFL_STATUS_WIN) { res.value = (int8_t)(TAFL_F_WINNER(st.flags) == start_side ? 1 : -1); res.reason = (uint8_t)TAFL_F_REASON(st.flags); }
+        else if (status == TAFL_STATUS_DRAW) { res.value = 0; res.reason = (uint8_t)(8 + TAFL_F_REASON(st.flags)); res.winner = 0; }
+        else { res.value = 0; res.reason = (uint8_t)(stuck ? TAFL_ROLLOUT_REASON_STUCK : TAFL_ROLLOUT_REASON_PLY_CAP); res.winner = 0; }
+    }
+};
+
+// ---- host-side construction of Consts (pure integer set-up; runs on the CPU in both builds) ----------------------
+template <int NL, int W>
+inline int make_consts(const tafl_rules& r, uint32_t n, Consts<NL>& C) {
+    if (n < 3 || n > (uint32_t)W || n > 15) return -1;
+    auto setb = [](Bits<NL>& b, uint32_t idx) { b.w[idx >> 5] |= 1u << (idx & 31); };
+    auto zero = [](Bits<NL>& b) { for (int i = 0; i < NL; ++i) b.w[i] = 0; };
+    zero(C.board); zero(C.col0); zero(C.coln); zero(C.row0); zero(C.rown); zero(C.edge); zero(C.corners); zero(C.throne); zero(C.throne_nb);
+    for (uint32_t rr = 0; rr < n; ++rr) for (uint32_t cc = 0; cc < n; ++cc) {
+        const uint32_t i = rr * (uint32_t)W + cc;
+        setb(C.board, i);
+        if (cc == 0) setb(C.col0, i);
+        if (cc == n - 1) setb(C.coln, i);
+        if (rr == 0) setb(C.row0, i);
+        if (rr == n - 1) setb(C.rown, i);
+        if (cc == 0 || rr == 0 || cc == n - 1 || rr == n - 1) setb(C.edge, i);
+        if ((rr == 0 || rr == n - 1) && (cc == 0 || cc == n - 1)) setb(C.corners, i);
+    }
+    const uint32_t t = n / 2;                                         // SpecialTiles::from, geometry.rs:13-25
+    C.throne_sq = t * (uint32_t)W + t; setb(C.throne, C.throne_sq);
+    if (t >= 1) { setb(C.throne_nb, (t - 1) * W + t); setb(C.throne_nb, t * W + t - 1); }
+    if (t + 1 < n) { setb(C.throne_nb, (t + 1) * W + t); setb(C.throne_nb, t * W + t + 1); }
+    C.n = n; C.w = (uint32_t)W; C.rules = r;
+    const uint32_t psbit[3] = {1u /*Soldier<<0*/, 9u /*Soldier<<8*/, 8u /*King<<8*/};
+    for (int c = 0; c < 3; ++c) {
+        const bool is_king = c == CLS_KING;
+        auto has = [&](uint16_t set) { return ((set >> psbit[c]) & 1u) != 0; };
+        zero(C.land_forbid[c]); zero(C.pass_forbid[c]); zero(C.hostile_special[c]);
+        if (!has(r.may_enter_corners)) for (int i = 0; i < NL; ++i) { C.land_forbid[c].w[i] |= C.corners.w[i]; C.pass_forbid[c].w[i] |= C.corners.w[i]; }
+        if (r.throne_movement == TAFL_THRONE_NOENTRY || (r.throne_movement == TAFL_THRONE_KINGENTRY && !is_king))
+            for (int i = 0; i < NL; ++i) C.land_forbid[c].w[i] |= C.throne.w[i];
+        if (r.throne_movement == TAFL_THRONE_NOPASS || (r.throne_movement == TAFL_THRONE_KINGPASS && !is_king))
+            for (int i = 0; i < NL; ++i) C.pass_forbid[c].w[i] |= C.throne.w[i];
+        if (has(r.hostility_throne)) for (int i = 0; i < NL; ++i) C.hostile_special[c].w[i] |= C.throne.w[i];
+        if (has(r.hostility_corners)) for (int i = 0; i < NL; ++i) C.hostile_special[c].w[i] |= C.corners.w[i];
+        C.slow[c] = has(r.slow_pieces) ? 1u : 0u;
+        C.edge_hostile[c] = has(r.hostility_edge) ? 1u : 0u;
+    }
+    bool same = C.slow[CLS_KING] == C.slow[CLS_DEF];
+    for (int i = 0; i < NL; ++i) same = same && C.land_forbid[CLS_KING].w[i] == C.land_forbid[CLS_DEF].w[i] && C.pass_forbid[CLS_KING].w[i] == C.pass_forbid[CLS_DEF].w[i];
+    C.king_like_soldier = same ? 1u : 0u;
+    return 0;
+}
+
+// ---- ABI <-> device state conversion (host side) -------------------------------------------------------------------------
+template <int NL>
+inline void state_from_abi(const tafl_state& a, DState<NL>& s) {
+    constexpr int L64 = NL / 2;
+    for (int i = 0; i < L64; ++i) {
+        s.att.w[2 * i] = (uint32_t)a.att[i]; s.att.w[2 * i + 1] = (uint32_t)(a.att[i] >> 32);
+        s.def.w[2 * i] = (uint32_t)a.def[i]; s.def.w[2 * i + 1] = (uint32_t)(a.def[i] >> 32);
+    }
+    const uint32_t krow = s.def.w[NL - 1] >> 28, kcol = s.att.w[NL - 1] >> 28;     // get_king, board/state.rs:127-131
+    s.att.w[NL - 1] &= 0x0FFFFFFFu; s.def.w[NL - 1] &= 0x0FFFFFFFu;
+    for (int i = 0; i < 4; ++i) s.rep[i] = a.rep_ring[i];
+    s.turn = a.turn; s.psc = a.plays_since_capture;
+    s.reps = (uint32_t)a.attacker_reps | ((uint32_t)a.defender_reps << 16);
+    s.flags = (a.side_to_play ? TAFL_F_SIDE : 0u) | (a.attacker_mid_pair ? TAFL_F_AMID : 0u) | (a.defender_mid_pair ? TAFL_F_DMID : 0u)
+            | ((uint32_t)(a.status & 3) << 3) | ((uint32_t)(a.reason & 15) << 5) | ((a.winner ? 1u : 0u) << 9) | (krow << 16) | (kcol << 20);
+}
+template <int NL>
+inline void state_to_abi(const DState<NL>& s, uint8_t side_len, tafl_state& a) {
+    constexpr int L64 = NL / 2;
+    a = tafl_state{};
+    uint32_t aw[NL], dw[NL];
+    for (int i = 0; i < NL; ++i) { aw[i] = s.att.w[i]; dw[i] = s.def.w[i]; }
+    aw[NL - 1] = (aw[NL - 1] & 0x0FFFFFFFu) | (TAFL_F_KCOL(s.flags) << 28);
+    dw[NL - 1] = (dw[NL - 1] & 0x0FFFFFFFu) | (TAFL_F_KROW(s.flags) << 28);
+    for (int i = 0; i < L64; ++i) {
+        a.att[i] = (uint64_t)aw[2 * i] | ((uint64_t)aw[2 * i + 1] << 32);
+        a.def[i] = (uint64_t)dw[2 * i] | ((uint64_t)dw[2 * i + 1] << 32);
+    }
+    for (int i = 0; i < 4; ++i) a.rep_ring[i] = s.rep[i];
+    a.turn = s.turn; a.plays_since_capture = s.psc;
+    a.attacker_reps = (uint16_t)(s.reps & 0xFFFFu); a.defender_reps = (uint16_t)(s.reps >> 16);
+    a.attacker_mid_pair = (s.flags & TAFL_F_AMID) ? 1 : 0; a.defender_mid_pair = (s.flags & TAFL_F_DMID) ? 1 : 0;
+    a.side_to_play = (s.flags & TAFL_F_SIDE) ? TAFL_DEFENDER : TAFL_ATTACKER;
+    a.status = (uint8_t)TAFL_F_STATUS(s.flags); a.reason = (uint8_t)TAFL_F_REASON(s.flags);
+    a.winner = (uint8_t)((a.status == TAFL_STATUS_WIN && TAFL_F_WINNER(s.flags)) ? TAFL_DEFENDER : TAFL_ATTACKER);
+    a.side_len = side_len;
+}
+
+}  // namespace tafl

@@ -1,0 +1,117 @@
+// hostsim.cpp — TEST HARNESS ONLY.  Compiles the product's per-game device functions
+// (alphazeroforhnefatafl_amd/csrc/tafl_ops.hpp) for the HOST with g++ and drives them in plain
+// CPU loops, so that the bit-parallel engine can be differential-tested against the literal oracle
+// in the build container (which has no GPU).  The product library never links this file and has no
+// CPU path; the GPU parity tests (tests/test_gpu_parity.py) check the real kernels.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../alphazeroforhnefatafl_amd/csrc/tafl_ops.hpp"
+
+using namespace tafl;
+
+template <int NL, int W>
+struct Host {
+    using O = Ops<NL, W>;
+    using S = DState<NL>;
+    using K = Consts<NL>;
+    static int consts(const tafl_rules* r, uint8_t n, K& C) { return make_consts<NL, W>(*r, n, C); }
+
+    static int movegen(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t cnt, uint32_t* counts, uint32_t* masks, uint32_t mw) {
+        K C; if (consts(r, n, C)) return -1;
+        for (uint32_t g = 0; g < cnt; ++g) {
+            S s; state_from_abi<NL>(st[g], s);
+            uint32_t* m = masks ? masks + (size_t)g * mw : nullptr;
+            if (m) memset(m, 0, sizeof(uint32_t) * mw);
+            const uint32_t c = O::movegen(s, C, m);
+            if (counts) counts[g] = c;
+        }
+        return 0;
+    }
+    static int validate(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t cnt, const tafl_play* plays, uint8_t* codes) {
+        K C; if (consts(r, n, C)) return -1;
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); codes[g] = (uint8_t)O::validate(s, plays[g], C); }
+        return 0;
+    }
+    static int step(const tafl_rules* r, uint8_t n, tafl_state* st, uint32_t cnt, const tafl_play* plays, tafl_effects* eff) {
+        K C; if (consts(r, n, C)) return -1;
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::step(s, plays[g], C, eff ? &eff[g] : nullptr); state_to_abi<NL>(s, n, st[g]); }
+        return 0;
+    }
+    static int step_kth(const tafl_rules* r, uint8_t n, tafl_state* st, uint32_t cnt, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff) {
+        K C; if (consts(r, n, C)) return -1;
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::step_kth(s, ranks[g], C, out_plays ? &out_plays[g] : nullptr, eff ? &eff[g] : nullptr); state_to_abi<NL>(s, n, st[g]); }
+        return 0;
+    }
+    static int side_can_play(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t cnt, uint8_t side, uint8_t* out) {
+        K C; if (consts(r, n, C)) return -1;
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); out[g] = O::side_can_play(s, side ? 1u : 0u, C) ? 1 : 0; }
+        return 0;
+    }
+    static int rollout(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t cnt, uint64_t seed, uint32_t sim, uint32_t max_plies, uint64_t base, tafl_rollout_result* out) {
+        K C; if (consts(r, n, C)) return -1;
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::rollout(s, seed, base + g, sim, max_plies, C, out[g]); }
+        return 0;
+    }
+    static int random_advance(const tafl_rules* r, uint8_t n, tafl_state* st, uint32_t cnt, uint64_t seed, const uint32_t* plies, uint64_t base) {
+        K C; if (consts(r, n, C)) return -1;
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::random_advance(s, seed, base + g, plies[g], C); state_to_abi<NL>(s, n, st[g]); }
+        return 0;
+    }
+    static int mcts(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t G, const tafl_mcts_params* p, uint64_t base,
+                    tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) {
+        K C; if (consts(r, n, C)) return -1;
+        using IO = StateIO<NL>;
+        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1);
+        std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS);
+        std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
+        std::vector<Edge> edges((size_t)M.edge_cap * G);
+        std::vector<uint32_t> ntop(G), etop(G), leaf(G);
+        std::vector<uint8_t> kind(G), fault(G); std::vector<int8_t> rv(G);
+        M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
+        M.leaf = leaf.data(); M.kind = kind.data(); M.rvalue = rv.data(); M.fault = fault.data();
+        memset(stats, 0, sizeof *stats);
+        for (uint32_t g = 0; g < G; ++g) { S s; state_from_abi<NL>(st[g], s); O::mcts_init_game(M, g, s, C); }
+        for (uint32_t i = 0; i < p->n_sims; ++i) {
+            for (uint32_t g = 0; g < G; ++g) {
+                LaneStats ls; memset(&ls, 0, sizeof ls);
+                O::mcts_backup(M, g);
+                O::mcts_select_expand(M, g, p->c_puct, C, ls);
+                stats->sims += ls.sims; stats->tree_depth_sum += ls.depth; stats->children_scanned += ls.scanned;
+                stats->terminal_hits += ls.terminal_hits; stats->faults += ls.faults;
+            }
+            for (uint32_t g = 0; g < G; ++g) {
+                LaneStats ls; memset(&ls, 0, sizeof ls);
+                O::mcts_rollout(M, g, p->seed, base + g, p->sim_offset + i, p->max_rollout_plies, C, ls);
+                stats->rollouts += ls.rollouts; stats->rollout_plies += ls.rollout_plies;
+                if (ls.rollouts) stats->reason_hist[ls.reason & 15]++;
+            }
+        }
+        for (uint32_t g = 0; g < G; ++g) O::mcts_backup(M, g);
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t k = O::mcts_root_children(M, g, C, out_children + (size_t)g * max_children, max_children);
+            if (out_n) out_n[g] = k;
+        }
+        return 0;
+    }
+};
+
+#define DISPATCH(call)                                              \
+    switch (word_bits) {                                            \
+        case 64:  return Host<2, 7>::call;                          \
+        case 128: return Host<4, 11>::call;                         \
+        case 256: return Host<8, 15>::call;                         \
+        default:  return -2;                                        \
+    }
+
+extern "C" {
+int hs_movegen(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint32_t* counts, uint32_t* masks, uint32_t mw) { DISPATCH(movegen(r, n, st, cnt, counts, masks, mw)) }
+int hs_validate(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_play* plays, uint8_t* codes) { DISPATCH(validate(r, n, st, cnt, plays, codes)) }
+int hs_step(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const tafl_play* plays, tafl_effects* eff) { DISPATCH(step(r, n, st, cnt, plays, eff)) }
+int hs_step_kth(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff) { DISPATCH(step_kth(r, n, st, cnt, ranks, out_plays, eff)) }
+int hs_side_can_play(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint8_t side, uint8_t* out) { DISPATCH(side_can_play(r, n, st, cnt, side, out)) }
+int hs_rollout(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint64_t seed, uint32_t sim, uint32_t max_plies, uint64_t base, tafl_rollout_result* out) { DISPATCH(rollout(r, n, st, cnt, seed, sim, max_plies, base, out)) }
+int hs_random_advance(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, uint64_t seed, const uint32_t* plies, uint64_t base) { DISPATCH(random_advance(r, n, st, cnt, seed, plies, base)) }
+int hs_mcts(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_mcts_params* p, uint64_t base, tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) { DISPATCH(mcts(r, n, st, cnt, p, base, out_children, max_children, out_n, stats)) }
+}

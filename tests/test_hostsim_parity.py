@@ -1,0 +1,140 @@
+"""Differential tests: the product's bit-parallel engine (device code compiled for the host,
+tests/hostsim) against the literal oracle, on seeded random games and synthetic positions.
+CPU only.  The same comparisons run against the real HIP kernels in tests/test_gpu_parity.py.
+"""
+import ctypes as C
+import random
+
+import pytest
+
+from alphazeroforhnefatafl_amd import abi
+from alphazeroforhnefatafl_amd.abi import TaflMctsParams
+from oracle import oracle as orc
+from tests.hostsim.hostsim import HostSim
+from tests import parity_util as pu
+
+
+def _mk(name):
+    rules, fen, wb = pu.CONFIGS[name]
+    n = abi.fen_side_len(fen)
+    return rules, fen, wb, n, orc.GameLogic(rules, n), HostSim(rules, n, wb)
+
+
+@pytest.mark.parametrize("name", list(pu.CONFIGS))
+def test_lockstep_games_step_kth(name):
+    """Play seeded random games ply by ply; at every ply compare legal-move masks and the full post-state."""
+    rules, fen, wb, n, lg, hs = _mk(name)
+    G, T = 96, 220
+    rng = random.Random(1234)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    for t in range(T):
+        oc, om = orc.batch_movegen(lg, states, G, wb)
+        hc, hm = hs.movegen(states, G)
+        assert list(oc) == list(hc), (name, t)
+        assert bytes(om) == bytes(hm), (name, t)
+        ranks = (C.c_uint32 * G)(*[rng.randrange(1 << 30) for _ in range(G)])
+        a = pu.clone_states(states, G)
+        b = pu.clone_states(states, G)
+        op, oe = orc.batch_step_kth(lg, a, G, wb, ranks)
+        hp, he = hs.step_kth(b, G, ranks)
+        for g in range(G):
+            assert pu.play_tuple4(op[g]) == pu.play_tuple4(hp[g]), (name, t, g, pu.describe_state(states[g], wb))
+            assert pu.effects_tuple(oe[g]) == pu.effects_tuple(he[g]), (name, t, g, pu.describe_state(states[g], wb), pu.play_tuple4(op[g]))
+        if not pu.states_equal(a, b, G):
+            g = pu.first_state_diff(a, b, G)
+            raise AssertionError((name, t, g, pu.describe_state(states[g], wb), pu.play_tuple4(op[g]),
+                                  pu.describe_state(a[g], wb), pu.describe_state(b[g], wb)))
+        states = a
+        # restart finished games so the batch keeps exercising play
+        if t % 50 == 49:
+            fresh = pu.start_states(orc, fen, rules.starting_side, wb, 1)[0]
+            for g in range(G):
+                if states[g].status != abi.ONGOING:
+                    C.memmove(C.byref(states, g * C.sizeof(abi.TaflState)), C.byref(fresh), C.sizeof(abi.TaflState))
+
+
+@pytest.mark.parametrize("name", ["copenhagen11", "brandubh7", "tablut9", "magpie7", "copenhagen13", "koch7"])
+def test_synthetic_positions(name):
+    """Random (unreachable) positions: masks, validate codes for arbitrary plays, one step, side_can_play."""
+    rules, fen, wb, n, lg, hs = _mk(name)
+    rng = random.Random(99)
+    G = 1500
+    states = pu.random_board_states(rng, n, wb, G)
+    oc, om = orc.batch_movegen(lg, states, G, wb)
+    hc, hm = hs.movegen(states, G)
+    for g in range(G):
+        assert oc[g] == hc[g], (name, g, pu.describe_state(states[g], wb))
+    assert bytes(om) == bytes(hm)
+    plays = pu.random_plays(rng, n, G)
+    codes = hs.validate(states, G, plays)
+    for g in range(G):
+        st = orc.GameState.from_abi(states[g], wb)
+        assert lg.validate_play(plays[g], st) == codes[g], (name, g, pu.describe_state(states[g], wb), pu.play_tuple4(plays[g]))
+    for side in (abi.ATTACKER, abi.DEFENDER):
+        out = hs.side_can_play(states, G, side)
+        for g in range(0, G, 7):
+            st = orc.GameState.from_abi(states[g], wb)
+            assert lg.side_can_play(side, st) == bool(out[g]), (name, g, side)
+    # arbitrary (mostly invalid) plays through do_play
+    a = pu.clone_states(states, G)
+    b = pu.clone_states(states, G)
+    oe = orc.batch_step(lg, a, G, wb, plays)
+    he = hs.step(b, G, plays)
+    for g in range(G):
+        assert pu.effects_tuple(oe[g]) == pu.effects_tuple(he[g]), (name, g)
+    assert pu.states_equal(a, b, G)
+    # three legal plies from each synthetic position
+    for t in range(3):
+        ranks = (C.c_uint32 * G)(*[rng.randrange(1 << 30) for _ in range(G)])
+        a = pu.clone_states(states, G)
+        b = pu.clone_states(states, G)
+        op, oe = orc.batch_step_kth(lg, a, G, wb, ranks)
+        hp, he = hs.step_kth(b, G, ranks)
+        for g in range(G):
+            assert pu.play_tuple4(op[g]) == pu.play_tuple4(hp[g]), (name, t, g, pu.describe_state(states[g], wb))
+            assert pu.effects_tuple(oe[g]) == pu.effects_tuple(he[g]), (name, t, g, pu.describe_state(states[g], wb), pu.play_tuple4(op[g]))
+        if not pu.states_equal(a, b, G):
+            g = pu.first_state_diff(a, b, G)
+            raise AssertionError((name, t, g, pu.describe_state(states[g], wb), pu.play_tuple4(op[g]),
+                                  pu.describe_state(a[g], wb), pu.describe_state(b[g], wb)))
+        states = a
+
+
+@pytest.mark.parametrize("name", ["copenhagen11", "brandubh7", "tablut9", "copenhagen13"])
+def test_rollouts(name):
+    rules, fen, wb, n, lg, hs = _mk(name)
+    G = 200
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[i % 64 for i in range(G)])
+    a = pu.clone_states(states, G)
+    b = pu.clone_states(states, G)
+    orc.batch_random_advance(lg, a, G, wb, 1, plies, 1000)
+    hs.random_advance(b, G, 1, plies, 1000)
+    assert pu.states_equal(a, b, G)
+    ro = orc.batch_rollout(lg, a, G, wb, 5, 3, 300, 1000)
+    rh = hs.rollout(a, G, 5, 3, 300, 1000)
+    for g in range(G):
+        assert (ro[g].value, ro[g].status, ro[g].reason, ro[g].winner, ro[g].plies) == \
+               (rh[g].value, rh[g].status, rh[g].reason, rh[g].winner, rh[g].plies), (name, g)
+
+
+@pytest.mark.parametrize("name,sims,cpuct", [("copenhagen11", 48, 1.0), ("brandubh7", 200, 1.0), ("tablut9", 64, 1.5),
+                                             ("copenhagen13", 24, 1.0)])
+def test_mcts(name, sims, cpuct):
+    rules, fen, wb, n, lg, hs = _mk(name)
+    G = 24
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 5) % 40 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 11, plies, 77)
+    p = TaflMctsParams(sims, 200, cpuct, 42, 0, 0)
+    ok, on, ostats = orc.batch_mcts(lg, states, G, wb, p, 77)
+    hk, hn, hstats = hs.mcts(states, G, p, 77)
+    assert list(on) == list(hn)
+    for g in range(G):
+        for j in range(on[g]):
+            a, b = ok[g * 256 + j], hk[g * 256 + j]
+            assert (pu.play_tuple4(a.play), a.action, a.visits, float(a.q).hex()) == \
+                   (pu.play_tuple4(b.play), b.action, b.visits, float(b.q).hex()), (name, g, j)
+    for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+        assert getattr(ostats, f) == getattr(hstats, f), f
+    assert list(ostats.reason_hist) == list(hstats.reason_hist)
