@@ -1,0 +1,684 @@
+// tafl_capi.hip — HIP kernels (gfx950) + the C-ABI of include/taflhip.h.
+//
+// Execution shape: ONE GAME PER LANE, 64-lane workgroups (one wavefront), so that a 65 536-game
+// batch is 1 024 waves = one wave per SIMD on the 256 CUs x 4 SIMDs of an MI355X.  Whole game
+// states live in VGPRs for the duration of a kernel (a random playout never touches HBM between its
+// first load and its final 1-byte result).  Batch states are quad-plane SoA in HBM (16 B per lane per
+// load, 1 KiB per wave instruction); tree nodes are 64-B records (DESIGN.md "Data layout in HBM").
+// No CPU fallback exists: every compute entry point launches kernels or fails.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tafl_host.hpp"
+#include "tafl_ops.hpp"
+
+using namespace tafl;
+
+// --------------------------------------------------------------------------------------------------
+// kernels
+// --------------------------------------------------------------------------------------------------
+#define TAFL_BLOCK 64
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_fill(Quad* soa, uint32_t n, DState<NL> st) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g < n) StateIO<NL>::store_soa(soa, n, g, st);
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_movegen(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t* counts, uint32_t* masks, uint32_t mw) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    uint32_t* m = masks ? masks + (size_t)g * mw : nullptr;
+    if (m) for (uint32_t i = 0; i < mw; ++i) m[i] = 0;
+    const uint32_t c = Ops<NL, W>::movegen(st, C, m);
+    if (counts) counts[g] = c;
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_validate(Consts<NL> C, const Quad* soa, uint32_t n, const tafl_play* plays, uint8_t* codes) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    codes[g] = (uint8_t)Ops<NL, W>::validate(st, plays[g], C);
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_step(Consts<NL> C, Quad* soa, uint32_t n, const tafl_play* plays, tafl_effects* eff) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    tafl_effects e;
+    Ops<NL, W>::step(st, plays[g], C, &e);
+    StateIO<NL>::store_soa(soa, n, g, st);
+    if (eff) eff[g] = e;
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_step_kth(Consts<NL> C, Quad* soa, uint32_t n, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    tafl_effects e; tafl_play p;
+    Ops<NL, W>::step_kth(st, ranks[g], C, &p, &e);
+    StateIO<NL>::store_soa(soa, n, g, st);
+    if (eff) eff[g] = e;
+    if (out_plays) out_plays[g] = p;
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_side_can_play(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t side, uint8_t* out) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    out[g] = Ops<NL, W>::side_can_play(st, side, C) ? 1 : 0;
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_rollout(Consts<NL> C, const Quad* soa, uint32_t n, uint64_t seed, uint32_t sim, uint32_t max_plies,
+                                                        uint64_t base, tafl_rollout_result* out) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    tafl_rollout_result r;
+    Ops<NL, W>::rollout(st, seed, base + g, sim, max_plies, C, r);
+    out[g] = r;
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_random_advance(Consts<NL> C, Quad* soa, uint32_t n, uint64_t seed, const uint32_t* plies, uint64_t base) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    Ops<NL, W>::random_advance(st, seed, base + g, plies[g], C);
+    StateIO<NL>::store_soa(soa, n, g, st);
+}
+
+// ---- MCTS kernels ---------------------------------------------------------------------------------
+enum { ST_SIMS = 0, ST_ROLLOUTS, ST_PLIES, ST_DEPTH, ST_SCANNED, ST_TERMINAL, ST_FAULTS, ST_REASON0 = 8, ST_COUNT = 24 };
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void stat_add(unsigned long long* stats, int idx, uint32_t v) {
+    const uint32_t s = wave_sum(v);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[idx], (unsigned long long)s);
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_init(Consts<NL> C, const Quad* soa, MctsMem M) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, M.G, g, st);
+    Ops<NL, W>::mcts_init_game(M, g, st, C);
+}
+
+// backup of simulation i-1 fused with select/expand of simulation i (both walk the same tree arena)
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> C, MctsMem M, double c_puct, int do_backup, int do_select, unsigned long long* stats) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
+    if (g < M.G) {
+        if (do_backup) Ops<NL, W>::mcts_backup(M, g);
+        if (do_select) Ops<NL, W>::mcts_select_expand(M, g, c_puct, C, ls);
+    }
+    stat_add(stats, ST_SIMS, ls.sims); stat_add(stats, ST_DEPTH, ls.depth); stat_add(stats, ST_SCANNED, ls.scanned);
+    stat_add(stats, ST_TERMINAL, ls.terminal_hits); stat_add(stats, ST_FAULTS, ls.faults);
+}
+
+// the dominant kernel: one seeded random playout per game, state resident in registers
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_rollout(Consts<NL> C, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim, uint32_t max_plies,
+                                                             unsigned long long* stats) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
+    if (g < M.G) Ops<NL, W>::mcts_rollout(M, g, seed, base + g, sim, max_plies, C, ls);
+    stat_add(stats, ST_ROLLOUTS, ls.rollouts); stat_add(stats, ST_PLIES, ls.rollout_plies);
+    // termination-reason histogram: 16 ballots per wave
+    for (uint32_t r = 0; r < 16; ++r) {
+        const unsigned long long b = __ballot(ls.rollouts && ls.reason == r);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&stats[ST_REASON0 + r], (unsigned long long)__popcll(b));
+    }
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_root_children(Consts<NL> C, MctsMem M, tafl_root_child* out, uint32_t max_children, uint32_t* out_n) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    out_n[g] = Ops<NL, W>::mcts_root_children(M, g, C, out + (size_t)g * max_children, max_children);
+}
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_root_visits(Consts<NL> C, MctsMem M, uint32_t* out, uint32_t action_size) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    const NodeHdr h = M.hdr[g];
+    const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+    for (uint32_t j = 0; j < h.m; ++j) {
+        const Edge e = eb[j];
+        const NodeHdr ch = M.hdr[(size_t)e.child * M.G + g];
+        Move m; m.from = ch.mv_from; m.dir = ch.mv_dir; m.dist = ch.mv_dist; m.to = 0;
+        out[(size_t)g * action_size + Ops<NL, W>::action_of(m, C)] = e.n;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// host objects
+// --------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(TAFL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+
+enum { KC_MOVEGEN = 0, KC_STEP, KC_ROLLOUT, KC_MCTS_TREE, KC_MCTS_ROLLOUT, KC_MCTS_BACKUP, KC_COUNT };
+
+struct TimedSpan { hipEvent_t a, b; int cls; };
+
+struct tafl_ctx {
+    tafl_rules rules;
+    uint32_t n, word_bits, nl, w;
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    Consts<2> c2; Consts<4> c4; Consts<8> c8;
+    bool timing;
+    std::vector<TimedSpan> spans;
+    double acc_ms[KC_COUNT]; uint64_t acc_n[KC_COUNT];
+};
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) return -1;
+        cap = bytes; return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct tafl_batch {
+    tafl_ctx* ctx;
+    uint32_t n;
+    Quad* soa;                       // quad-plane SoA: [QUADS][n]
+    DevBuf plays, effects, counts, masks, codes, ranks, results, out_plays, u8out, plies;
+    // MCTS
+    MctsMem mem; bool has_mem; uint32_t reserved_sims;
+    DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, rvalue, fault, stats, children, children_n, visits;
+    tafl_mcts_stats last_stats; bool ran;
+};
+
+static int quads_of(const tafl_ctx* c) { return (2 * (int)c->nl + 8) / 4; }
+static uint32_t grid_of(uint32_t n) { return (n + TAFL_BLOCK - 1) / TAFL_BLOCK; }
+
+#define DISPATCH_NLW(ctx, STMT)                                                                     \
+    do {                                                                                            \
+        if ((ctx)->nl == 2) { constexpr int NL = 2, W = 7; const Consts<2>& CC = (ctx)->c2; (void)CC; (void)W; STMT; }        \
+        else if ((ctx)->nl == 4) { constexpr int NL = 4, W = 11; const Consts<4>& CC = (ctx)->c4; (void)CC; (void)W; STMT; }  \
+        else { constexpr int NL = 8, W = 15; const Consts<8>& CC = (ctx)->c8; (void)CC; (void)W; STMT; }                      \
+    } while (0)
+
+struct SpanGuard {
+    tafl_ctx* c; int idx;
+    SpanGuard(tafl_ctx* ctx, int cls) : c(ctx), idx(-1) {
+        if (!c->timing) return;
+        TimedSpan s; s.cls = cls;
+        if (hipEventCreate(&s.a) != hipSuccess) return;
+        if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
+        (void)hipEventRecord(s.a, c->stream);
+        c->spans.push_back(s); idx = (int)c->spans.size() - 1;
+    }
+    ~SpanGuard() { if (idx >= 0) (void)hipEventRecord(c->spans[idx].b, c->stream); }
+};
+
+static void drain_spans(tafl_ctx* c) {
+    for (auto& s : c->spans) {
+        (void)hipEventSynchronize(s.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->acc_ms[s.cls] += ms; c->acc_n[s.cls] += 1; }
+        (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+    }
+    c->spans.clear();
+}
+
+// --------------------------------------------------------------------------------------------------
+// C-ABI
+// --------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* tafl_last_error(void) { return g_err.c_str(); }
+int tafl_abi_version(void) { return TAFLHIP_ABI_VERSION; }
+int tafl_preset_rules(const char* name, tafl_rules* out) {
+    if (!name || !out) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    if (preset_rules(name, out)) return fail(TAFL_ERR_INVALID_ARG, std::string("unknown ruleset preset: ") + name);
+    return TAFL_OK;
+}
+const char* tafl_preset_board(const char* name) { return preset_board(name); }
+
+int tafl_ctx_create(const tafl_rules* rules, uint8_t side_len, uint32_t word_bits, int device, void* stream, tafl_ctx** out) {
+    if (!rules || !out) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    int l64, rw;
+    if (word_params(word_bits, &l64, &rw)) return fail(TAFL_ERR_INVALID_ARG, "word_bits must be 64, 128 or 256");
+    if (side_len < 3 || (int)side_len > rw || side_len > 15) return fail(TAFL_ERR_INVALID_ARG, "side_len does not fit the board word");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(TAFL_ERR_NO_DEVICE, "no HIP device visible: taflhip has no CPU path");
+    if (device < 0 || device >= ndev) return fail(TAFL_ERR_INVALID_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    tafl_ctx* c = new (std::nothrow) tafl_ctx();
+    if (!c) return fail(TAFL_ERR_OOM, "out of host memory");
+    c->rules = *rules; c->n = side_len; c->word_bits = word_bits; c->nl = (uint32_t)l64 * 2; c->w = (uint32_t)rw; c->device = device;
+    c->timing = false;
+    for (int i = 0; i < KC_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
+    int rc = 0;
+    if (c->nl == 2) rc = make_consts<2, 7>(*rules, side_len, c->c2);
+    else if (c->nl == 4) rc = make_consts<4, 11>(*rules, side_len, c->c4);
+    else rc = make_consts<8, 15>(*rules, side_len, c->c8);
+    if (rc) { delete c; return fail(TAFL_ERR_INVALID_ARG, "bad rules / geometry"); }
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(TAFL_ERR_HIP, "hipStreamCreate failed"); } c->own_stream = true; }
+    *out = c;
+    return TAFL_OK;
+}
+
+int tafl_ctx_destroy(tafl_ctx* c) {
+    if (!c) return TAFL_OK;
+    (void)hipSetDevice(c->device);
+    drain_spans(c);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TAFL_OK;
+}
+
+void* tafl_ctx_stream(tafl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+uint32_t tafl_action_size(const tafl_ctx* c) { return c ? c->n * c->n * 4u * (c->n - 1) : 0; }
+uint32_t tafl_action_mask_words(const tafl_ctx* c) { return (tafl_action_size(c) + 31) / 32; }
+int tafl_action_encode(const tafl_ctx* c, tafl_play p, uint32_t* action) {
+    if (!c || !action) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    const uint32_t dist = (uint32_t)(p.disp < 0 ? -(int)p.disp : (int)p.disp);
+    if (p.from_row >= c->n || p.from_col >= c->n || dist == 0 || dist > c->n - 1) return fail(TAFL_ERR_INVALID_ARG, "play outside the action space");
+    const uint32_t dir = p.axis == TAFL_AXIS_VERTICAL ? (p.disp > 0 ? 0u : 1u) : (p.disp > 0 ? 2u : 3u);
+    *action = ((uint32_t)p.from_row * c->n + p.from_col) * 4u * (c->n - 1) + dir * (c->n - 1) + (dist - 1);
+    return TAFL_OK;
+}
+int tafl_action_decode(const tafl_ctx* c, uint32_t a, tafl_play* play) {
+    if (!c || !play || a >= tafl_action_size(c)) return fail(TAFL_ERR_INVALID_ARG, "action out of range");
+    const uint32_t per = 4u * (c->n - 1), sq = a / per, rem = a % per, dir = rem / (c->n - 1), dist = rem % (c->n - 1) + 1;
+    play->from_row = (uint8_t)(sq / c->n); play->from_col = (uint8_t)(sq % c->n);
+    play->axis = dir < 2 ? TAFL_AXIS_VERTICAL : TAFL_AXIS_HORIZONTAL;
+    play->disp = (int8_t)((dir & 1) ? -(int)dist : (int)dist);
+    return TAFL_OK;
+}
+
+int tafl_state_from_fen(const tafl_ctx* c, const char* fen, uint8_t side, tafl_state* out) {
+    if (!c || !fen || !out) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    std::string err;
+    if (fen_to_state(fen, side, c->word_bits, out, &err)) return fail(TAFL_ERR_PARSE, err);
+    if (out->side_len != c->n) return fail(TAFL_ERR_PARSE, "FEN side length differs from the context's side_len");
+    return TAFL_OK;
+}
+
+int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
+    if (!c || !out || n == 0) return fail(TAFL_ERR_INVALID_ARG, "bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    tafl_batch* b = new (std::nothrow) tafl_batch();
+    if (!b) return fail(TAFL_ERR_OOM, "out of host memory");
+    b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr;
+    memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats);
+    const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
+    if (hipMalloc((void**)&b->soa, bytes) != hipSuccess) { delete b; return fail(TAFL_ERR_OOM, "hipMalloc(batch states) failed"); }
+    if (hipMemsetAsync(b->soa, 0, bytes, c->stream) != hipSuccess) { (void)hipFree(b->soa); delete b; return fail(TAFL_ERR_HIP, "hipMemsetAsync failed"); }
+    *out = b;
+    return TAFL_OK;
+}
+
+int tafl_batch_destroy(tafl_batch* b) {
+    if (!b) return TAFL_OK;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->soa) (void)hipFree(b->soa);
+    DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
+                      &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
+                      &b->children, &b->children_n, &b->visits};
+    for (DevBuf* d : bufs) d->release();
+    delete b;
+    return TAFL_OK;
+}
+
+uint32_t tafl_batch_size(const tafl_batch* b) { return b ? b->n : 0; }
+
+int tafl_sync(tafl_ctx* c) {
+    if (!c) return fail(TAFL_ERR_INVALID_ARG, "null ctx");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_batch_reset_fen(tafl_batch* b, const char* fen, uint8_t side) {
+    if (!b || !fen) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    tafl_ctx* c = b->ctx;
+    tafl_state st;
+    int rc = tafl_state_from_fen(c, fen, side, &st);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    DISPATCH_NLW(c, {
+        DState<NL> ds; state_from_abi<NL>(st, ds);
+        hipLaunchKernelGGL((k_fill<NL, W>), dim3(grid_of(b->n)), dim3(TAFL_BLOCK), 0, c->stream, b->soa, b->n, ds);
+    });
+    HIPCHK(hipGetLastError());
+    return TAFL_OK;
+}
+
+int tafl_batch_upload(tafl_batch* b, const tafl_state* states, uint32_t first, uint32_t count) {
+    if (!b || !states || first + count > b->n || count == 0) return fail(TAFL_ERR_INVALID_ARG, "bad range");
+    tafl_ctx* c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const int Q = quads_of(c);
+    std::vector<Quad> stage((size_t)Q * count);
+    for (uint32_t i = 0; i < count; ++i) {
+        if (states[i].side_len != c->n) return fail(TAFL_ERR_INVALID_ARG, "state.side_len differs from the context's side_len");
+        uint32_t v[24];
+        DISPATCH_NLW(c, { DState<NL> ds; state_from_abi<NL>(states[i], ds); StateIO<NL>::pack(ds, v); });
+        for (int q = 0; q < Q; ++q) { Quad t; t.x = v[4 * q]; t.y = v[4 * q + 1]; t.z = v[4 * q + 2]; t.w = v[4 * q + 3]; stage[(size_t)q * count + i] = t; }
+    }
+    for (int q = 0; q < Q; ++q)
+        HIPCHK(hipMemcpyAsync(b->soa + (size_t)q * b->n + first, stage.data() + (size_t)q * count, sizeof(Quad) * count, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_batch_download(tafl_batch* b, tafl_state* states, uint32_t first, uint32_t count) {
+    if (!b || !states || first + count > b->n || count == 0) return fail(TAFL_ERR_INVALID_ARG, "bad range");
+    tafl_ctx* c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const int Q = quads_of(c);
+    std::vector<Quad> stage((size_t)Q * count);
+    for (int q = 0; q < Q; ++q)
+        HIPCHK(hipMemcpyAsync(stage.data() + (size_t)q * count, b->soa + (size_t)q * b->n + first, sizeof(Quad) * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < count; ++i) {
+        uint32_t v[24];
+        for (int q = 0; q < Q; ++q) { const Quad t = stage[(size_t)q * count + i]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+        DISPATCH_NLW(c, { DState<NL> ds; StateIO<NL>::unpack(v, ds); state_to_abi<NL>(ds, (uint8_t)c->n, states[i]); });
+    }
+    return TAFL_OK;
+}
+
+// ---- hot path --------------------------------------------------------------------------------------
+#define NEED(buf, bytes) do { if ((buf).ensure(bytes)) return fail(TAFL_ERR_OOM, "hipMalloc(workspace) failed"); } while (0)
+
+int tafl_movegen(tafl_batch* b, uint32_t* out_counts, uint32_t* out_masks) {
+    if (!b) return fail(TAFL_ERR_INVALID_ARG, "null batch");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n, mw = tafl_action_mask_words(c);
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->counts, sizeof(uint32_t) * n);
+    if (out_masks) NEED(b->masks, sizeof(uint32_t) * (size_t)n * mw);
+    {
+        SpanGuard sg(c, KC_MOVEGEN);
+        DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
+                                           (uint32_t*)b->counts.p, out_masks ? (uint32_t*)b->masks.p : nullptr, mw));
+    }
+    HIPCHK(hipGetLastError());
+    if (out_counts) HIPCHK(hipMemcpyAsync(out_counts, b->counts.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    if (out_masks) HIPCHK(hipMemcpyAsync(out_masks, b->masks.p, sizeof(uint32_t) * (size_t)n * mw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_validate(tafl_batch* b, const tafl_play* plays, uint8_t* out_codes) {
+    if (!b || !plays || !out_codes) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->plays, sizeof(tafl_play) * n); NEED(b->codes, n);
+    HIPCHK(hipMemcpyAsync(b->plays.p, plays, sizeof(tafl_play) * n, hipMemcpyHostToDevice, c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_validate<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
+                                       (const tafl_play*)b->plays.p, (uint8_t*)b->codes.p));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_codes, b->codes.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_step(tafl_batch* b, const tafl_play* plays, tafl_effects* out_effects) {
+    if (!b || !plays) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->plays, sizeof(tafl_play) * n);
+    if (out_effects) NEED(b->effects, sizeof(tafl_effects) * n);
+    HIPCHK(hipMemcpyAsync(b->plays.p, plays, sizeof(tafl_play) * n, hipMemcpyHostToDevice, c->stream));
+    {
+        SpanGuard sg(c, KC_STEP);
+        DISPATCH_NLW(c, hipLaunchKernelGGL((k_step<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
+                                           (const tafl_play*)b->plays.p, out_effects ? (tafl_effects*)b->effects.p : nullptr));
+    }
+    HIPCHK(hipGetLastError());
+    if (out_effects) HIPCHK(hipMemcpyAsync(out_effects, b->effects.p, sizeof(tafl_effects) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_step_kth(tafl_batch* b, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* out_effects) {
+    if (!b || !ranks) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->ranks, sizeof(uint32_t) * n);
+    if (out_plays) NEED(b->out_plays, sizeof(tafl_play) * n);
+    if (out_effects) NEED(b->effects, sizeof(tafl_effects) * n);
+    HIPCHK(hipMemcpyAsync(b->ranks.p, ranks, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
+    {
+        SpanGuard sg(c, KC_STEP);
+        DISPATCH_NLW(c, hipLaunchKernelGGL((k_step_kth<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
+                                           (const uint32_t*)b->ranks.p, out_plays ? (tafl_play*)b->out_plays.p : nullptr,
+                                           out_effects ? (tafl_effects*)b->effects.p : nullptr));
+    }
+    HIPCHK(hipGetLastError());
+    if (out_plays) HIPCHK(hipMemcpyAsync(out_plays, b->out_plays.p, sizeof(tafl_play) * n, hipMemcpyDeviceToHost, c->stream));
+    if (out_effects) HIPCHK(hipMemcpyAsync(out_effects, b->effects.p, sizeof(tafl_effects) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_side_can_play(tafl_batch* b, uint8_t side, uint8_t* out) {
+    if (!b || !out) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->u8out, n);
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_side_can_play<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
+                                       side ? 1u : 0u, (uint8_t*)b->u8out.p));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, b->u8out.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_rollout(tafl_batch* b, uint64_t seed, uint32_t sim, uint32_t max_plies, uint64_t game_id_base, tafl_rollout_result* out) {
+    if (!b || !out) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->results, sizeof(tafl_rollout_result) * n);
+    {
+        SpanGuard sg(c, KC_ROLLOUT);
+        DISPATCH_NLW(c, hipLaunchKernelGGL((k_rollout<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, seed, sim, max_plies,
+                                           game_id_base, (tafl_rollout_result*)b->results.p));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, b->results.p, sizeof(tafl_rollout_result) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_random_advance(tafl_batch* b, uint64_t seed, const uint32_t* plies, uint64_t game_id_base) {
+    if (!b || !plies) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->plies, sizeof(uint32_t) * n);
+    HIPCHK(hipMemcpyAsync(b->plies.p, plies, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_random_advance<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, seed,
+                                       (const uint32_t*)b->plies.p, game_id_base));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+// ---- MCTS ----------------------------------------------------------------------------------------------
+int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
+    if (!b || max_sims == 0 || max_sims > 60000) return fail(TAFL_ERR_INVALID_ARG, "max_sims must be in 1..60000");
+    tafl_ctx* c = b->ctx; const size_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    if (b->has_mem && b->reserved_sims >= max_sims) return TAFL_OK;
+    const size_t node_cap = (size_t)max_sims + 1, edge_cap = 4 * ((size_t)max_sims + 1);
+    NEED(b->node_state, node_cap * n * quads_of(c) * sizeof(Quad));
+    NEED(b->hdr, node_cap * n * sizeof(NodeHdr));
+    NEED(b->edges, edge_cap * n * sizeof(Edge));
+    NEED(b->node_top, n * 4); NEED(b->edge_top, n * 4); NEED(b->leaf, n * 4);
+    NEED(b->kind, n); NEED(b->rvalue, n); NEED(b->fault, n);
+    NEED(b->stats, sizeof(unsigned long long) * ST_COUNT);
+    b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
+    b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
+    b->mem.kind = (uint8_t*)b->kind.p; b->mem.rvalue = (int8_t*)b->rvalue.p; b->mem.fault = (uint8_t*)b->fault.p;
+    b->mem.G = b->n; b->mem.node_cap = (uint32_t)node_cap; b->mem.edge_cap = (uint32_t)edge_cap;
+    b->has_mem = true; b->reserved_sims = max_sims;
+    return TAFL_OK;
+}
+
+int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base) {
+    if (!b || !p) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    if (p->flags != 0) return fail(TAFL_ERR_UNSUPPORTED, "tafl_mcts_params.flags must be 0");
+    if (p->n_sims == 0) return fail(TAFL_ERR_INVALID_ARG, "n_sims must be > 0");
+    int rc = tafl_mcts_reserve(b, p->n_sims);
+    if (rc) return rc;
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    MctsMem M = b->mem;
+    M.node_cap = p->n_sims + 1; M.edge_cap = b->mem.edge_cap;
+    unsigned long long* st = (unsigned long long*)b->stats.p;
+    HIPCHK(hipMemsetAsync(st, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_init<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, M));
+    for (uint32_t i = 0; i < p->n_sims; ++i) {
+        {
+            SpanGuard sg(c, KC_MCTS_TREE);
+            DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_tree<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, i > 0 ? 1 : 0, 1, st));
+        }
+        {
+            SpanGuard sg(c, KC_MCTS_ROLLOUT);
+            DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->seed, game_id_base,
+                                               p->sim_offset + i, p->max_rollout_plies, st));
+        }
+    }
+    {
+        SpanGuard sg(c, KC_MCTS_BACKUP);
+        DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_tree<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, 1, 0, st));
+    }
+    HIPCHK(hipGetLastError());
+    b->ran = true;
+    return TAFL_OK;
+}
+
+int tafl_mcts_get_stats(tafl_batch* b, tafl_mcts_stats* out) {
+    if (!b || !out || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "no MCTS run on this batch");
+    tafl_ctx* c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    unsigned long long h[ST_COUNT];
+    HIPCHK(hipMemcpyAsync(h, b->stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memset(out, 0, sizeof *out);
+    out->sims = h[ST_SIMS]; out->rollouts = h[ST_ROLLOUTS]; out->rollout_plies = h[ST_PLIES]; out->tree_depth_sum = h[ST_DEPTH];
+    out->children_scanned = h[ST_SCANNED]; out->terminal_hits = h[ST_TERMINAL]; out->faults = h[ST_FAULTS];
+    for (int i = 0; i < 16; ++i) out->reason_hist[i] = h[ST_REASON0 + i];
+    return TAFL_OK;
+}
+
+int tafl_mcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_children, uint32_t* out_n) {
+    if (!b || !out || !out_n || max_children == 0 || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->children, sizeof(tafl_root_child) * (size_t)n * max_children); NEED(b->children_n, sizeof(uint32_t) * n);
+    HIPCHK(hipMemsetAsync(b->children.p, 0, sizeof(tafl_root_child) * (size_t)n * max_children, c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_root_children<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem,
+                                       (tafl_root_child*)b->children.p, max_children, (uint32_t*)b->children_n.p));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, b->children.p, sizeof(tafl_root_child) * (size_t)n * max_children, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(out_n, b->children_n.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (uint32_t g = 0; g < n; ++g) if (out_n[g] > max_children) return fail(TAFL_ERR_CAPACITY, "max_children too small for some game");
+    return TAFL_OK;
+}
+
+int tafl_mcts_root_visits(tafl_batch* b, uint32_t* out) {
+    if (!b || !out || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n, as = tafl_action_size(c);
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->visits, sizeof(uint32_t) * (size_t)n * as);
+    HIPCHK(hipMemsetAsync(b->visits.p, 0, sizeof(uint32_t) * (size_t)n * as, c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_root_visits<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, (uint32_t*)b->visits.p, as));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, b->visits.p, sizeof(uint32_t) * (size_t)n * as, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+// probs of src/mcts.py:40-53 computed on the host from the device's root visit counts (float64, same op order)
+int tafl_mcts_policy(tafl_batch* b, double temp, double* out) {
+    if (!b || !out || !b->ran || temp < 0) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n, as = tafl_action_size(c);
+    std::vector<uint32_t> counts((size_t)n * as);
+    int rc = tafl_mcts_root_visits(b, counts.data());
+    if (rc) return rc;
+    for (uint32_t g = 0; g < n; ++g) {
+        const uint32_t* cg = counts.data() + (size_t)g * as; double* og = out + (size_t)g * as;
+        if (temp == 0) {
+            uint32_t best = 0, arg = 0;
+            for (uint32_t a = 0; a < as; ++a) if (cg[a] > best) { best = cg[a]; arg = a; }
+            for (uint32_t a = 0; a < as; ++a) og[a] = 0.0;
+            og[arg] = 1.0;
+        } else {
+            const double ex = 1.0 / temp; double sum = 0.0;
+            for (uint32_t a = 0; a < as; ++a) { og[a] = pow((double)cg[a], ex); sum += og[a]; }
+            for (uint32_t a = 0; a < as; ++a) og[a] = og[a] / sum;
+        }
+    }
+    return TAFL_OK;
+}
+
+int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visits) {
+    if (!b || !out_plays || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    const uint32_t n = b->n, mc = 4u * (b->ctx->n - 1) * 40u;
+    std::vector<tafl_root_child> kids((size_t)n * mc); std::vector<uint32_t> cnt(n);
+    int rc = tafl_mcts_root_children(b, kids.data(), mc, cnt.data());
+    if (rc) return rc;
+    for (uint32_t g = 0; g < n; ++g) {
+        uint32_t best = 0; tafl_play bp; memset(&bp, 0, sizeof bp);
+        for (uint32_t j = 0; j < cnt[g]; ++j) { const tafl_root_child& k = kids[(size_t)g * mc + j]; if (k.visits > best) { best = k.visits; bp = k.play; } }
+        out_plays[g] = bp; if (out_visits) out_visits[g] = best;
+    }
+    return TAFL_OK;
+}
+
+// ---- timing ---------------------------------------------------------------------------------------------
+int tafl_timing_enable(tafl_ctx* c, int enable) { if (!c) return fail(TAFL_ERR_INVALID_ARG, "null ctx"); c->timing = enable != 0; return TAFL_OK; }
+int tafl_timing_reset(tafl_ctx* c) {
+    if (!c) return fail(TAFL_ERR_INVALID_ARG, "null ctx");
+    (void)hipSetDevice(c->device);
+    drain_spans(c);
+    for (int i = 0; i < KC_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
+    return TAFL_OK;
+}
+int tafl_timing_get(tafl_ctx* c, int cls, double* total_ms, uint64_t* launches) {
+    if (!c || cls < 0 || cls >= KC_COUNT) return fail(TAFL_ERR_INVALID_ARG, "bad kernel class");
+    (void)hipSetDevice(c->device);
+    drain_spans(c);
+    if (total_ms) *total_ms = c->acc_ms[cls];
+    if (launches) *launches = c->acc_n[cls];
+    return TAFL_OK;
+}
+
+}  // extern "C"

@@ -129,7 +129,7 @@ struct Ops {
                     r = andn(r, bit_at<NL>(to));
                     const Move m = E::resolve(st, (uint32_t)d, to);
                     const uint32_t a = action_of(m, C);
-                    mask[a >> 5] |= 1u << (a & 31);
+                    if (a < C.n * C.n * 4u * (C.n - 1)) mask[a >> 5] |= 1u << (a & 31);   // never write outside the game's mask
                 }
             }
         }
@@ -141,7 +141,7 @@ struct Ops {
     }
     // tafl_step: do_play (logic.rs:827-834)
     static TAFL_HD void step(S& st, tafl_play p, const K& C, tafl_effects* eff) {
-        Move m;
+        Move m; m.from = m.to = m.dir = m.dist = 0;
         const int code = E::validate(st, p, st.flags & TAFL_F_SIDE, C, &m);
         tafl_effects e; caps_to_effects(bz<NL>(), 0, e);
         if (code == TAFL_PLAY_OK) {

@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's `GameLogic` surface (game/game/logic.rs:62-880), batched.
+
+`BatchedGameLogic(rules, side_len)` plays the role of `GameLogic::new(rules, board_length)`;
+`GameBatch` holds n `GameState<T>` values (game/game/state.rs:119-146) resident in HBM.  Method names,
+argument meaning and error behaviour follow the reference: per-game rule errors come back as
+`PlayInvalid` codes (game/error.rs:49-70), never as exceptions; only library / HIP failures raise.
+All compute runs in HIP kernels through the C-ABI (include/taflhip.h); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import abi
+from ._lib import check, lib
+from .abi import (TaflEffects, TaflMctsParams, TaflMctsStats, TaflPlay, TaflRolloutResult, TaflRootChild, TaflState)
+
+KC_MOVEGEN, KC_STEP, KC_ROLLOUT, KC_MCTS_TREE, KC_MCTS_ROLLOUT, KC_MCTS_BACKUP = range(6)
+
+
+class BatchedGameLogic:
+    """GameLogic{rules, board_geo} bound to one GPU (tafl_ctx)."""
+
+    def __init__(self, rules: abi.Ruleset, side_len: int, word_bits: int | None = None, device: int = 0,
+                 stream: int | None = None):
+        self.rules = rules
+        self.side_len = side_len
+        self.word_bits = word_bits or abi.word_bits_for(side_len)
+        self.device = device
+        self._c_rules = rules.to_c()
+        self._h = C.c_void_p()
+        check(lib().tafl_ctx_create(C.byref(self._c_rules), side_len, self.word_bits, device,
+                                    C.c_void_p(stream) if stream else None, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().tafl_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def action_size(self) -> int:
+        return lib().tafl_action_size(self._h)
+
+    @property
+    def mask_words(self) -> int:
+        return lib().tafl_action_mask_words(self._h)
+
+    def sync(self):
+        check(lib().tafl_sync(self._h))
+
+    def new_batch(self, n_games: int, fen: str | None = None, side_to_play: int | None = None) -> "GameBatch":
+        b = GameBatch(self, n_games)
+        if fen is not None:
+            b.reset_fen(fen, self.rules.starting_side if side_to_play is None else side_to_play)
+        return b
+
+    def state_from_fen(self, fen: str, side_to_play: int | None = None) -> TaflState:
+        st = TaflState()
+        side = self.rules.starting_side if side_to_play is None else side_to_play
+        check(lib().tafl_state_from_fen(self._h, fen.encode(), side, C.byref(st)))
+        return st
+
+    # timing of the kernel classes (HIP events on the ctx stream)
+    def timing_enable(self, on: bool = True):
+        check(lib().tafl_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        check(lib().tafl_timing_reset(self._h))
+
+    def timing_get(self, kernel_class: int):
+        ms, k = C.c_double(), C.c_uint64()
+        check(lib().tafl_timing_get(self._h, kernel_class, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
+
+class GameBatch:
+    """n GameState<T> values in HBM + the batched GameLogic operations over them."""
+
+    def __init__(self, logic: BatchedGameLogic, n_games: int):
+        self.logic = logic
+        self.n = n_games
+        self._h = C.c_void_p()
+        check(lib().tafl_batch_create(logic._h, n_games, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().tafl_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state movement -------------------------------------------------------------------------
+    def reset_fen(self, fen: str, side_to_play: int):
+        """GameState::new(fen, side) for every game (game/game/state.rs:136-145)."""
+        check(lib().tafl_batch_reset_fen(self._h, fen.encode(), side_to_play))
+
+    def upload(self, states, first: int = 0, count: int | None = None):
+        count = self.n - first if count is None else count
+        check(lib().tafl_batch_upload(self._h, states, first, count))
+
+    def download(self, first: int = 0, count: int | None = None):
+        count = self.n - first if count is None else count
+        out = (TaflState * count)()
+        check(lib().tafl_batch_download(self._h, out, first, count))
+        return out
+
+    # -- GameLogic surface -------------------------------------------------------------------------
+    def iter_plays(self, want_masks: bool = True):
+        """All legal plays of the side to move, per game: (counts, dense action masks) — get_all_possible_moves
+        (game/main.rs:33-43) = iter_occupied x GameLogic::iter_plays (logic.rs:850-856)."""
+        counts = (C.c_uint32 * self.n)()
+        masks = (C.c_uint32 * (self.n * self.logic.mask_words))() if want_masks else None
+        check(lib().tafl_movegen(self._h, counts, masks))
+        return counts, masks
+
+    def validate_play(self, plays):
+        """GameLogic::validate_play (logic.rs:219-222): PlayInvalid code per game (0 = Ok)."""
+        codes = (C.c_uint8 * self.n)()
+        check(lib().tafl_validate(self._h, plays, codes))
+        return codes
+
+    def do_play(self, plays, want_effects: bool = True):
+        """GameLogic::do_play (logic.rs:827-834) for every game; invalid plays leave that game unchanged."""
+        eff = (TaflEffects * self.n)() if want_effects else None
+        check(lib().tafl_step(self._h, plays, eff))
+        return eff
+
+    def do_kth_play(self, ranks):
+        """Game i plays its (ranks[i] mod count)-th legal play in canonical order."""
+        eff = (TaflEffects * self.n)()
+        plays = (TaflPlay * self.n)()
+        check(lib().tafl_step_kth(self._h, ranks, plays, eff))
+        return plays, eff
+
+    def side_can_play(self, side: int):
+        """GameLogic::side_can_play (logic.rs:837-846)."""
+        out = (C.c_uint8 * self.n)()
+        check(lib().tafl_side_can_play(self._h, side, out))
+        return out
+
+    # -- rollouts / MCTS ------------------------------------------------------------------------------
+    def rollout(self, seed: int, sim: int, max_plies: int, game_id_base: int = 0):
+        out = (TaflRolloutResult * self.n)()
+        check(lib().tafl_rollout(self._h, seed, sim, max_plies, game_id_base, out))
+        return out
+
+    def random_advance(self, seed: int, plies, game_id_base: int = 0):
+        check(lib().tafl_random_advance(self._h, seed, plies, game_id_base))
+
+    def mcts_reserve(self, max_sims: int):
+        check(lib().tafl_mcts_reserve(self._h, max_sims))
+
+    def mcts_run(self, n_sims: int, c_puct: float, seed: int, max_rollout_plies: int, game_id_base: int = 0,
+                 sim_offset: int = 0):
+        p = TaflMctsParams(n_sims, max_rollout_plies, c_puct, seed, sim_offset, 0)
+        check(lib().tafl_mcts_run(self._h, C.byref(p), game_id_base))
+
+    def mcts_stats(self) -> TaflMctsStats:
+        st = TaflMctsStats()
+        check(lib().tafl_mcts_get_stats(self._h, C.byref(st)))
+        return st
+
+    def mcts_root_children(self, max_children: int = 256):
+        kids = (TaflRootChild * (self.n * max_children))()
+        cnt = (C.c_uint32 * self.n)()
+        check(lib().tafl_mcts_root_children(self._h, kids, max_children, cnt))
+        return kids, cnt
+
+    def mcts_root_visits(self):
+        out = (C.c_uint32 * (self.n * self.logic.action_size))()
+        check(lib().tafl_mcts_root_visits(self._h, out))
+        return out
+
+    def mcts_policy(self, temp: float = 1.0):
+        out = (C.c_double * (self.n * self.logic.action_size))()
+        check(lib().tafl_mcts_policy(self._h, temp, out))
+        return out
+
+    def mcts_best_play(self):
+        plays = (TaflPlay * self.n)()
+        visits = (C.c_uint32 * self.n)()
+        check(lib().tafl_mcts_best_play(self._h, plays, visits))
+        return plays, visits

@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's headline metric on MI355X.
+
+One "step" = one pass of the hot path over one batch: `tafl_mcts_run` of S simulations
+(select / expand / random-rollout / backup as lock-step HIP kernels) on 65 536 concurrent 11x11 Copenhagen games
+per GPU, from the start position (BASELINE.json configs[2]; configs[1] is a parity case, configs[3] is this
+workload at N=8).  States are resident in HBM before the timed region; nothing crosses PCIe inside it.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (k_mcts_rollout): algorithmic HBM bytes per launch / live HIP-event launch time
+  cpu_baseline  the oracle (literal C restatement of the reference rules crate + mcts.py arithmetic) timed on the
+                host, 1 thread, on a bounded sample of the same workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GAMES_PER_GPU = 65536
+SIDE, WORD_BITS = 11, 128
+STATE_BYTES = 64                 # SoA state bytes per 11x11 game (SURVEY.md §8d S_g)
+ROLLOUT_BYTES_PER_GAME = 68      # S_g read + 4 B result (register-resident rollout)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(n_sims, c_puct, seed, max_plies, budget_s=20.0):
+    """Oracle timed on host cores: same workload (Copenhagen start, S sims/root), bounded sample of games."""
+    from alphazeroforhnefatafl_amd import abi
+    from alphazeroforhnefatafl_amd.abi import TaflMctsParams
+    from oracle import oracle as orc
+    lg = orc.GameLogic(abi.rules.COPENHAGEN, SIDE)
+    st = orc.GameState(abi.boards.COPENHAGEN, abi.ATTACKER, WORD_BITS).to_abi()
+    one = (abi.TaflState * 1)(st)
+    p = TaflMctsParams(n_sims, max_plies, c_puct, seed, 0, 0)
+    games = sims = plies = 0
+    t0 = time.perf_counter()
+    while True:
+        _, _, stats = orc.batch_mcts(lg, one, 1, WORD_BITS, p, games)
+        games += 1
+        sims += stats.sims
+        plies += stats.rollout_plies
+        dt = time.perf_counter() - t0
+        if dt > budget_s or games >= 4096:
+            break
+    return {"value": sims / dt, "unit": "sims/s", "cores": 1, "kind": "port",
+            "env_steps_per_sec": plies / dt,
+            "sample": f"{games} games x {n_sims} sims of the bench workload (Copenhagen 11x11 start, cap {max_plies}), "
+                      f"{dt:.1f} s on 1 host thread (literal C oracle, gcc -O2)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sims", type=int, default=64, help="MCTS simulations per root (BASELINE config 3: 64/256/1000)")
+    ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="concurrent games per GPU")
+    ap.add_argument("--max-plies", type=int, default=512)
+    ap.add_argument("--cpuct", type=float, default=1.0)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from alphazeroforhnefatafl_amd import abi
+    from alphazeroforhnefatafl_amd.engine import KC_MCTS_BACKUP, KC_MCTS_ROLLOUT, KC_MCTS_TREE, BatchedGameLogic
+
+    stream = torch.cuda.Stream()
+    logic = BatchedGameLogic(abi.rules.COPENHAGEN, SIDE, WORD_BITS, device=local_rank, stream=stream.cuda_stream)
+    G = args.games
+    batch = logic.new_batch(G, abi.boards.COPENHAGEN)        # synthetic data: every game at the start position
+    batch.mcts_reserve(args.sims)
+    base = rank * G                                           # contiguous global game-id shards, no collective on the data path
+
+    def step():
+        batch.mcts_run(args.sims, args.cpuct, args.seed, args.max_plies, game_id_base=base)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    logic.timing_reset()
+    logic.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    logic.timing_enable(False)
+    stats = batch.mcts_stats()                                # counters of the last step
+    roll_ms, roll_n = logic.timing_get(KC_MCTS_ROLLOUT)
+    tree_ms, tree_n = logic.timing_get(KC_MCTS_TREE)
+    bk_ms, bk_n = logic.timing_get(KC_MCTS_BACKUP)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    total_sims = float(world) * G * args.sims * args.steps
+    plies_per_step = float(stats.rollout_plies)
+    total_plies = plies_per_step * args.steps * world          # identical workload per rank up to RNG ids
+    if rank == 0:
+        avg_roll_s = (roll_ms / max(roll_n, 1)) * 1e-3
+        achieved = (ROLLOUT_BYTES_PER_GAME * G) / avg_roll_s / 1e9 if avg_roll_s > 0 else 0.0
+        d_bar = stats.tree_depth_sum / max(stats.sims, 1)
+        c_bar = stats.children_scanned / max(stats.tree_depth_sum, 1)
+        bytes_per_sim = d_bar * (64 + 16 * c_bar) + 32 + 2 * STATE_BYTES + 4     # SURVEY.md §8d formula
+        out = {
+            "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: full MCTS (select/expand/random-rollout/backup), "
+                                   "65536 concurrent 11x11 Copenhagen games per GPU from the start position",
+                       "games_per_gpu": G, "sims_per_root": args.sims, "max_rollout_plies": args.max_plies,
+                       "c_puct": args.cpuct, "seed": args.seed, "sharding": f"game-id ranges x{world}, no collectives"},
+            "env_steps_per_sec": total_plies / elapsed,
+            "plies_per_rollout": plies_per_step / max(stats.rollouts, 1),
+            "mcts": {"sims": int(stats.sims), "rollouts": int(stats.rollouts), "terminal_hits": int(stats.terminal_hits),
+                     "mean_select_depth": d_bar, "mean_children_scanned": c_bar, "faults": int(stats.faults),
+                     "reason_hist": [int(x) for x in stats.reason_hist],
+                     "algorithmic_bytes_per_sim": bytes_per_sim,
+                     "hbm_frac_sims": (total_sims / elapsed / world) * bytes_per_sim / (HBM_PEAK_GBS * 1e9)},
+            "kernels_ms": {"k_mcts_rollout": {"avg": roll_ms / max(roll_n, 1), "launches": int(roll_n)},
+                           "k_mcts_tree": {"avg": tree_ms / max(tree_n, 1), "launches": int(tree_n)},
+                           "k_mcts_tree(final backup)": {"avg": bk_ms / max(bk_n, 1), "launches": int(bk_n)}},
+            "roofline": {"kernel": "k_mcts_rollout", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "register-resident playout: 68 algorithmic bytes per game per launch; the binding limit is "
+                                 "integer VALU issue/latency, see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.sims, args.cpuct, args.seed, args.max_plies)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

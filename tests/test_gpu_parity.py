@@ -1,0 +1,434 @@
+"""GPU parity tests: the HIP kernels, called through the C-ABI (include/taflhip.h), against the CPU oracle
+on identical seeded inputs, the committed golden fixtures (reference KATs, reference-mcts.py vectors) and
+size-independent properties at BASELINE.json's full batch size.  Bit-exact everywhere (integer / index work;
+float64 Qsa compared as bit patterns).  Needs a real MI355X: `pytest -m gpu`.
+"""
+import collections
+import ctypes as C
+import json
+import os
+import random
+
+import pytest
+
+from alphazeroforhnefatafl_amd import abi
+from alphazeroforhnefatafl_amd.abi import TaflMctsParams, TaflPlay, TaflState
+from oracle import oracle as orc
+from tests import parity_util as pu
+from tests.kat_util import KATS, REASON_CODE, play, ruleset, side_of, status_tuple, tiles
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LOGICS = {}
+
+
+def gpu_logic(rules, n, wb):
+    from alphazeroforhnefatafl_amd.engine import BatchedGameLogic
+    key = (bytes(rules.to_c()), n, wb)
+    if key not in _LOGICS:
+        _LOGICS[key] = BatchedGameLogic(rules, n, wb)
+    return _LOGICS[key]
+
+
+def gpu_batch(rules, n, wb, states, G):
+    lg = gpu_logic(rules, n, wb)
+    b = lg.new_batch(G)
+    b.upload(states)
+    return b
+
+
+def _mk(name):
+    rules, fen, wb = pu.CONFIGS[name]
+    n = abi.fen_side_len(fen)
+    return rules, fen, wb, n, orc.GameLogic(rules, n)
+
+
+def test_native_library_is_loaded():
+    """The HIP extension (in-tree libtaflhip.so) must be the thing that runs: no silent fallback exists."""
+    from alphazeroforhnefatafl_amd import _lib
+    L = _lib.lib()
+    assert os.path.basename(_lib.LIB_PATH) == "libtaflhip.so" and os.path.exists(_lib.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libtaflhip.so" in f.read()
+    assert L.tafl_abi_version() == abi.ABI_VERSION
+    lg = gpu_logic(abi.rules.COPENHAGEN, 11, 128)
+    assert lg.action_size == 2420 and lg.mask_words == 76
+
+
+def test_upload_download_roundtrip_and_fen():
+    rng = random.Random(3)
+    for n, wb in ((7, 64), (11, 128), (9, 128), (13, 256)):
+        states = pu.random_board_states(rng, n, wb, 300)
+        b = gpu_batch(abi.rules.COPENHAGEN, n, wb, states, 300)
+        back = b.download()
+        assert pu.states_equal(states, back, 300), (n, wb)
+    for name, (rules, fen, wb) in pu.CONFIGS.items():
+        n = abi.fen_side_len(fen)
+        lg = gpu_logic(rules, n, wb)
+        b = lg.new_batch(70, fen)
+        got = b.download()
+        want = orc.GameState(fen, rules.starting_side, wb).to_abi()
+        for g in (0, 33, 69):
+            assert bytes(got[g]) == bytes(want), name
+        assert bytes(lg.state_from_fen(fen)) == bytes(want), name
+
+
+def test_config2_movegen_and_step_4096_copenhagen():
+    """BASELINE.json configs[1]: batch 4096 11x11 Copenhagen games, move-gen + step kernels, bit-exact vs CPU."""
+    rules, fen, wb, n, lg = _mk("copenhagen11")
+    G = 4096
+    glg = gpu_logic(rules, n, wb)
+    b = glg.new_batch(G, fen)
+    plies = (C.c_uint32 * G)(*[i % 64 for i in range(G)])
+    b.random_advance(1, plies, 0)
+    ostates = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    orc.batch_random_advance(lg, ostates, G, wb, 1, plies, 0)
+    gstates = b.download()
+    assert pu.states_equal(ostates, gstates, G), pu.first_state_diff(ostates, gstates, G)
+    rng = random.Random(5)
+    for t in range(6):
+        oc, om = orc.batch_movegen(lg, ostates, G, wb)
+        gc, gm = b.iter_plays()
+        assert list(oc) == list(gc), t
+        assert bytes(om) == bytes(gm), t
+        ranks = (C.c_uint32 * G)(*[rng.randrange(1 << 30) for _ in range(G)])
+        op, oe = orc.batch_step_kth(lg, ostates, G, wb, ranks)
+        gp, ge = b.do_kth_play(ranks)
+        for g in range(G):
+            assert pu.play_tuple4(op[g]) == pu.play_tuple4(gp[g]), (t, g)
+            assert pu.effects_tuple(oe[g]) == pu.effects_tuple(ge[g]), (t, g)
+        gstates = b.download()
+        assert pu.states_equal(ostates, gstates, G), (t, pu.first_state_diff(ostates, gstates, G))
+
+
+@pytest.mark.parametrize("name", list(pu.CONFIGS))
+def test_lockstep_games(name):
+    rules, fen, wb, n, lg = _mk(name)
+    G, T = 192, 120
+    rng = random.Random(1234)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    b = gpu_batch(rules, n, wb, states, G)
+    for t in range(T):
+        if t % 10 == 0:
+            oc, om = orc.batch_movegen(lg, states, G, wb)
+            gc, gm = b.iter_plays()
+            assert list(oc) == list(gc), (name, t)
+            assert bytes(om) == bytes(gm), (name, t)
+        ranks = (C.c_uint32 * G)(*[rng.randrange(1 << 30) for _ in range(G)])
+        op, oe = orc.batch_step_kth(lg, states, G, wb, ranks)
+        gp, ge = b.do_kth_play(ranks)
+        for g in range(G):
+            assert pu.play_tuple4(op[g]) == pu.play_tuple4(gp[g]), (name, t, g)
+            assert pu.effects_tuple(oe[g]) == pu.effects_tuple(ge[g]), (name, t, g)
+        if t % 10 == 9 or t == T - 1:
+            got = b.download()
+            assert pu.states_equal(states, got, G), (name, t, pu.first_state_diff(states, got, G))
+
+
+def _expand_compare_gpu(rules, n, wb, lst, tag):
+    lg = orc.GameLogic(rules, n)
+    G = len(lst)
+    states = pu.states_array(lst)
+    b = gpu_batch(rules, n, wb, states, G)
+    oc, om = orc.batch_movegen(lg, states, G, wb)
+    gc, gm = b.iter_plays()
+    assert list(oc) == list(gc), tag
+    assert bytes(om) == bytes(gm), tag
+    arr, ranks, total, src = pu.expand_all(states, G, oc)
+    cov = collections.Counter()
+    if total == 0:
+        return cov
+    a = pu.clone_states(arr, total)
+    op, oe = orc.batch_step_kth(lg, a, total, wb, ranks)
+    b2 = gpu_batch(rules, n, wb, arr, total)
+    gp, ge = b2.do_kth_play(ranks)
+    got = b2.download()
+    for i in range(total):
+        assert pu.play_tuple4(op[i]) == pu.play_tuple4(gp[i]), (tag, i)
+        assert pu.effects_tuple(oe[i]) == pu.effects_tuple(ge[i]), (tag, i, pu.describe_state(arr[i], wb), pu.play_tuple4(op[i]))
+        cov[(oe[i].status, oe[i].reason)] += 1
+    assert pu.states_equal(a, got, total), (tag, pu.first_state_diff(a, got, total))
+    b.close(); b2.close()
+    return cov
+
+
+def test_rare_rules_crafted_positions():
+    """Enclosure win, exit fort, shieldwall, sparse endgames: every legal play of crafted positions."""
+    rng = random.Random(21)
+    C11 = abi.rules.COPENHAGEN
+    cov = collections.Counter()
+    for n, wb in ((11, 128), (13, 256), (9, 128)):
+        cov += _expand_compare_gpu(C11, n, wb, pu.enclosure_positions(rng, n, wb, 150), ("encl", n))
+        cov += _expand_compare_gpu(C11, n, wb, pu.exit_fort_positions(rng, n, wb, 150), ("fort", n))
+        cov += _expand_compare_gpu(C11, n, wb, pu.shieldwall_positions(rng, n, wb, 200), ("sw", n))
+        cov += _expand_compare_gpu(C11, n, wb, pu.sparse_endgame_positions(rng, n, wb, 150), ("sparse", n))
+    cov += _expand_compare_gpu(abi.rules.BRANDUBH, 7, 64, pu.enclosure_positions(rng, 7, 64, 150), ("encl", 7))
+    cov += _expand_compare_gpu(abi.rules.BRANDUBH, 7, 64, pu.sparse_endgame_positions(rng, 7, 64, 200), ("sparse", 7))
+    cov += _expand_compare_gpu(abi.rules.TABLUT, 9, 128, pu.sparse_endgame_positions(rng, 9, 128, 200), ("sparse-tablut", 9))
+    dense = pu.random_board_states(rng, 11, 128, 400, density=0.7)
+    cov += _expand_compare_gpu(C11, 11, 128, [dense[i] for i in range(400)], ("dense", 11))
+    assert cov[(abi.WIN, abi.ENCLOSED)] >= 20, cov
+    assert cov[(abi.WIN, abi.EXIT_FORT)] >= 50, cov
+    assert cov[(abi.WIN, abi.KING_CAPTURED)] >= 10, cov
+    assert cov[(abi.WIN, abi.ALL_CAPTURED)] >= 1, cov
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_rulesets(seed):
+    rng = random.Random(2000 + seed)
+    rules = pu.random_ruleset(rng)
+    n, wb = rng.choice([(7, 64), (9, 128), (11, 128), (13, 256)])
+    lst = [s for s in pu.random_board_states(rng, n, wb, 100)] + pu.enclosure_positions(rng, n, wb, 30) + \
+        pu.shieldwall_positions(rng, n, wb, 40) + pu.sparse_endgame_positions(rng, n, wb, 40)
+    if n >= 9:
+        lst += pu.exit_fort_positions(rng, n, wb, 30)
+    _expand_compare_gpu(rules, n, wb, lst, ("fuzz", seed))
+    # validate codes for arbitrary plays
+    G = len(lst)
+    states = pu.states_array(lst)
+    plays = pu.random_plays(rng, n, G)
+    b = gpu_batch(rules, n, wb, states, G)
+    codes = b.validate_play(plays)
+    lg = orc.GameLogic(rules, n)
+    for g in range(G):
+        st = orc.GameState.from_abi(states[g], wb)
+        assert lg.validate_play(plays[g], st) == codes[g], (seed, g)
+    for side in (abi.ATTACKER, abi.DEFENDER):
+        out = b.side_can_play(side)
+        for g in range(0, G, 5):
+            st = orc.GameState.from_abi(states[g], wb)
+            assert lg.side_can_play(side, st) == bool(out[g]), (seed, g, side)
+    # arbitrary plays through do_play (mostly rejected: state must stay untouched, code must match)
+    a = pu.clone_states(states, G)
+    oe = orc.batch_step(lg, a, G, wb, plays)
+    ge = b.do_play(plays)
+    for g in range(G):
+        assert pu.effects_tuple(oe[g]) == pu.effects_tuple(ge[g]), (seed, g)
+    assert pu.states_equal(a, b.download(), G)
+
+
+@pytest.mark.parametrize("name,G,cap", [("copenhagen11", 1024, 512), ("brandubh7", 512, 256), ("tablut9", 512, 300),
+                                       ("copenhagen13", 256, 300), ("magpie7", 256, 200)])
+def test_rollouts(name, G, cap):
+    rules, fen, wb, n, lg = _mk(name)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 7) % 50 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 3, plies, 500)
+    b = gpu_batch(rules, n, wb, states, G)
+    ro = orc.batch_rollout(lg, states, G, wb, 5, 9, cap, 500)
+    rg = b.rollout(5, 9, cap, 500)
+    for g in range(G):
+        assert (ro[g].value, ro[g].status, ro[g].reason, ro[g].winner, ro[g].plies) == \
+               (rg[g].value, rg[g].status, rg[g].reason, rg[g].winner, rg[g].plies), (name, g)
+    assert pu.states_equal(states, b.download(), G), "tafl_rollout must not modify the batch"
+
+
+def test_kat_replay_through_the_c_abi():
+    """The reference's own unit tests (tests/golden/reference_kats.json) replayed on the GPU path."""
+    # test_iter_plays (game/game/mod.rs:137-207): legal sets per piece from the dense mask
+    for case in KATS["iter_plays"]["cases"]:
+        rules = ruleset(case["rules"])
+        lg = gpu_logic(rules, 7, case["word_bits"])
+        for side in (abi.ATTACKER, abi.DEFENDER):
+            b = lg.new_batch(1, case["fen"], side)
+            _, masks = b.iter_plays()
+            acts = [a for a in range(lg.action_size) if (masks[a >> 5] >> (a & 31)) & 1]
+            per_tile = collections.defaultdict(set)
+            for a in acts:
+                p = abi.action_decode(7, a)
+                per_tile[(p.from_row, p.from_col)].add(abi.play_to(p))
+            st = orc.GameState(case["fen"], side, case["word_bits"])
+            for q in case["queries"]:
+                pc = st.get_piece(tuple(q["tile"]))
+                if q["expected"] is None or pc is None or pc[1] != side:
+                    continue
+                assert per_tile[tuple(q["tile"])] == tiles(q["expected"]), q
+    # test_play_validity (logic.rs:923-1013) on 64/128/256-bit words
+    for wb in (64, 128, 256):
+        b = None
+        rules = None
+        for step in KATS["play_validity"]["script"]:
+            op = step["op"]
+            if op == "new":
+                rules = ruleset(step["rules"])
+                b = gpu_logic(rules, 7, wb).new_batch(1, step["fen"], side_of(step["side"], rules))
+            elif op in ("valid", "invalid"):
+                code = b.validate_play((TaflPlay * 1)(play(step["play"])))[0]
+                assert code == (0 if op == "valid" else REASON_CODE[step["reason"]]), (wb, step)
+            elif op == "do_play":
+                eff = b.do_play((TaflPlay * 1)(play(step["play"])))
+                assert eff[0].code == 0
+            elif op == "board_move":
+                st = orc.GameState.from_abi(b.download()[0], wb)
+                st.move_piece(tuple(step["from"]), tuple(step["to"]))
+                b.upload((TaflState * 1)(st.to_abi()))
+            elif op == "set_side":
+                st = b.download()
+                st[0].side_to_play = abi.ATTACKER if step["side"] == "A" else abi.DEFENDER
+                b.upload(st)
+    # test_play_outcome (logic.rs:1023-1079)
+    k = KATS["play_outcome"]
+    rules = ruleset(k["rules"])
+    for wb in (64, 128, 256):
+        for case in k["cases"]:
+            b = gpu_logic(rules, 7, wb).new_batch(1, k["fen"], side_of(case["side"], rules))
+            eff = b.do_play((TaflPlay * 1)(play(case["play"])))[0]
+            assert eff.code == 0 and (eff.status, eff.reason, eff.winner) == status_tuple(case["status"]), (wb, case)
+            assert _caps(eff, abi.row_width(wb)) == tiles(case["captures"]), (wb, case)
+    # test_strong_king_capture (logic.rs:1424-1462), test_linnaean_capture (:1465-1482)
+    k = KATS["strong_king_capture"]
+    for case in k["cases"]:
+        b = gpu_logic(ruleset(k["rules"]), 7, 64).new_batch(1, case["fen"], abi.ATTACKER)
+        eff = b.do_play((TaflPlay * 1)(play(case["play"])))[0]
+        assert _caps(eff, 7) == tiles(case["captures"]) and (eff.status, eff.reason, eff.winner) == status_tuple(case["outcome"]), case
+    k = KATS["linnaean_capture"]
+    b = gpu_logic(ruleset(k["rules"]), 9, 128).new_batch(1, k["fen"], abi.ATTACKER)
+    eff = b.do_play((TaflPlay * 1)(play(k["play"])))[0]
+    assert _caps(eff, 11) == tiles(k["captures"])
+    # test_repetitions (logic.rs:1406-1421)
+    k = KATS["repetitions"]
+    b = gpu_logic(ruleset(k["rules"]), 7, 64).new_batch(1, k["fen"], abi.ATTACKER)
+    for _ in range(k["cycles"]):
+        for s in k["cycle"]:
+            assert b.do_play((TaflPlay * 1)(abi.play_from_str(s)))[0].code == 0
+    st = b.download()[0]
+    assert (st.status, st.reason, st.winner) == status_tuple(k["status_after_cycles"])
+    eff = b.do_play((TaflPlay * 1)(abi.play_from_str(k["final_play"])))[0]
+    assert (eff.status, eff.reason, eff.winner) == status_tuple(k["final_status"])
+    # test_can_play (logic.rs:1388-1403), derived opening counts
+    k = KATS["can_play"]
+    for case in k["cases"]:
+        b = gpu_logic(ruleset(k["rules"]), 7, 64).new_batch(1, case["fen"], abi.ATTACKER)
+        assert bool(b.side_can_play(abi.ATTACKER)[0]) == case["attacker"]
+        assert bool(b.side_can_play(abi.DEFENDER)[0]) == case["defender"]
+    for case in KATS["derived_counts"]["cases"]:
+        n = abi.fen_side_len(case["fen"])
+        b = gpu_logic(ruleset(case["rules"]), n, abi.word_bits_for(n)).new_batch(3, case["fen"], abi.ATTACKER if case["side"] == "A" else abi.DEFENDER)
+        counts, _ = b.iter_plays(want_masks=False)
+        assert list(counts) == [case["count"]] * 3
+    # exit forts / shieldwalls (logic.rs:1090-1233) through do_play equivalence with the oracle are in the crafted tests
+
+
+def _caps(eff, rw):
+    out = set()
+    for limb in range(abi.MAX_LIMBS):
+        v = int(eff.captures[limb])
+        while v:
+            bpos = (v & -v).bit_length() - 1
+            bit = limb * 64 + bpos
+            out.add((bit // rw, bit % rw))
+            v &= v - 1
+    return out
+
+
+with open(os.path.join(HERE, "golden", "mcts_golden.json")) as f:
+    GOLD = json.load(f)
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_mcts_matches_reference_mcts_py_golden(case):
+    """Root statistics produced by the reference's src/mcts.py (tests/golden/make_mcts_golden.py) reproduced on the GPU."""
+    rules = abi.rules.BY_NAME[case["rules"]]
+    st = TaflState.from_buffer_copy(bytes.fromhex(case["state_hex"]))
+    G = 3                                  # the golden game plus two decoys with other ids in the same wave
+    arr = (TaflState * G)(st, st, st)
+    b = gpu_batch(rules, case["side_len"], case["word_bits"], arr, G)
+    # decoys get ids game_id+1, +2; the golden game is game 0 with base = game_id
+    b.mcts_run(case["n_sims"], case["cpuct"], case["seed"], case["max_plies"], game_id_base=case["game_id"])
+    kids, cnt = b.mcts_root_children(256)
+    got = [[kids[j].action, kids[j].visits, float(kids[j].q).hex()] for j in range(cnt[0])]
+    assert got == case["root_children"]
+    stats = b.mcts_stats()
+    assert stats.sims == G * case["n_sims"] and stats.faults == 0
+    # policy of mcts.py:48-53 at temp = 1
+    probs = b.mcts_policy(1.0)
+    nz = [(a, float(probs[a]).hex()) for a in range(b.logic.action_size) if probs[a] != 0]
+    assert nz == [tuple(x) for x in case["probs_temp1_nonzero"]]
+    assert pu.states_equal(arr, b.download(), G), "tafl_mcts_run must not modify the batch"
+
+
+@pytest.mark.parametrize("name,G,sims,cpuct,cap", [("copenhagen11", 64, 64, 1.0, 512), ("brandubh7", 128, 200, 1.0, 256),
+                                                  ("tablut9", 64, 96, 1.5, 300), ("copenhagen13", 32, 32, 1.0, 256)])
+def test_mcts_vs_oracle(name, G, sims, cpuct, cap):
+    """BASELINE config 3 parity: a fixed subset of games reproduced by the CPU oracle bit for bit."""
+    rules, fen, wb, n, lg = _mk(name)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    if name != "copenhagen11":
+        plies = (C.c_uint32 * G)(*[(i * 5) % 40 for i in range(G)])
+        orc.batch_random_advance(lg, states, G, wb, 11, plies, 77)
+    p = TaflMctsParams(sims, cap, cpuct, 2, 0, 0)
+    ok, on, ostats = orc.batch_mcts(lg, states, G, wb, p, 77)
+    b = gpu_batch(rules, n, wb, states, G)
+    b.mcts_run(sims, cpuct, 2, cap, game_id_base=77)
+    gk, gn = b.mcts_root_children(256)
+    assert list(on) == list(gn)
+    for g in range(G):
+        for j in range(on[g]):
+            x, y = ok[g * 256 + j], gk[g * 256 + j]
+            assert (pu.play_tuple4(x.play), x.action, x.visits, float(x.q).hex()) == \
+                   (pu.play_tuple4(y.play), y.action, y.visits, float(y.q).hex()), (name, g, j)
+    gs = b.mcts_stats()
+    for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+        assert getattr(ostats, f) == getattr(gs, f), f
+    assert list(ostats.reason_hist) == list(gs.reason_hist)
+    # best play / dense visits consistent with the children list
+    bp, bv = b.mcts_best_play()
+    dense = b.mcts_root_visits()
+    for g in range(G):
+        vs = [gk[g * 256 + j].visits for j in range(gn[g])]
+        assert bv[g] == max(vs)
+        assert pu.play_tuple4(bp[g]) == pu.play_tuple4(gk[g * 256 + vs.index(max(vs))].play)
+        for j in range(gn[g]):
+            assert dense[g * b.logic.action_size + gk[g * 256 + j].action] == gk[g * 256 + j].visits
+        assert sum(dense[g * b.logic.action_size:(g + 1) * b.logic.action_size]) == sum(vs)
+
+
+def test_full_size_properties_65536():
+    """BASELINE full size (65 536 concurrent 11x11 games): sharding invariance (results depend on the GLOBAL game id
+    only, so 1/2/4/8-GPU runs agree), oracle spot checks, and conservation properties."""
+    rules, fen, wb, n, lg = _mk("copenhagen11")
+    G = 65536
+    glg = gpu_logic(rules, n, wb)
+    big = glg.new_batch(G, fen)
+    sims, cap, seed = 8, 128, 2
+    big.mcts_run(sims, 1.0, seed, cap, game_id_base=0)
+    kids, cnt = big.mcts_root_children(16)
+    st = big.mcts_stats()
+    assert st.sims == G * sims and st.faults == 0
+    assert st.rollouts + st.terminal_hits == st.sims
+    assert sum(st.reason_hist) == st.rollouts
+    # every game: root visits sum to sims - 1 (the first simulation only expands the root, mcts.py:83-102)
+    for g in range(0, G, 97):
+        assert sum(kids[g * 16 + j].visits for j in range(cnt[g])) == sims - 1
+    # shard invariance: the second half as its own batch with game_id_base = G/2
+    half = glg.new_batch(G // 2, fen)
+    half.mcts_run(sims, 1.0, seed, cap, game_id_base=G // 2)
+    hk, hc = half.mcts_root_children(16)
+    for g in range(0, G // 2, 61):
+        a = [(kids[(G // 2 + g) * 16 + j].action, kids[(G // 2 + g) * 16 + j].visits, kids[(G // 2 + g) * 16 + j].q) for j in range(cnt[G // 2 + g])]
+        bb = [(hk[g * 16 + j].action, hk[g * 16 + j].visits, hk[g * 16 + j].q) for j in range(hc[g])]
+        assert a == bb, g
+    # oracle spot check on scattered game ids
+    ids = [0, 1, 63, 64, 4097, 32768, 65535]
+    p = TaflMctsParams(sims, cap, 1.0, seed, 0, 0)
+    one = pu.start_states(orc, fen, rules.starting_side, wb, 1)
+    for gid in ids:
+        ok, on, _ = orc.batch_mcts(lg, one, 1, wb, p, gid)
+        want = [(ok[j].action, ok[j].visits, float(ok[j].q).hex()) for j in range(on[0])]
+        got = [(kids[gid * 16 + j].action, kids[gid * 16 + j].visits, float(kids[gid * 16 + j].q).hex()) for j in range(cnt[gid])]
+        assert want == got, gid
+    # rollouts at full size: value/status consistency + oracle spot check
+    res = big.rollout(7, 0, 512, 0)
+    hist = collections.Counter()
+    for g in range(0, G, 13):
+        r = res[g]
+        hist[r.reason] += 1
+        assert r.plies <= 512
+        if r.status == abi.WIN:
+            assert r.value in (-1, 1) and (r.value == 1) == (r.winner == abi.ATTACKER)
+        else:
+            assert r.value == 0
+    oneres = orc.batch_rollout(lg, one, 1, wb, 7, 0, 512, 4097)
+    assert (oneres[0].value, oneres[0].reason, oneres[0].plies) == (res[4097].value, res[4097].reason, res[4097].plies)
+    assert pu.states_equal(pu.start_states(orc, fen, rules.starting_side, wb, 64), big.download(0, 64), 64)
