@@ -366,17 +366,28 @@ def state_words(st: TaflState, word_bits: int) -> tuple[int, int]:
 
 
 def action_size(side_len: int) -> int:
-    return side_len * side_len * 4 * (side_len - 1)
+    """n^2 * 2(n-1): every (from tile, destination on its row/column) pair — include/taflhip.h."""
+    return side_len * side_len * 2 * (side_len - 1)
 
 
 def action_encode(side_len: int, p: TaflPlay) -> int:
-    d = (0 if p.disp > 0 else 1) if p.axis == VERTICAL else (2 if p.disp > 0 else 3)
-    return (p.from_row * side_len + p.from_col) * 4 * (side_len - 1) + d * (side_len - 1) + abs(p.disp) - 1
+    n, m = side_len, side_len - 1
+    r, c, dist = p.from_row, p.from_col, abs(p.disp)
+    if p.axis == VERTICAL:
+        slot = dist - 1 if p.disp > 0 else (m - r) + dist - 1
+    else:
+        slot = m + dist - 1 if p.disp > 0 else m + (m - c) + dist - 1
+    return (r * n + c) * 2 * m + slot
 
 
 def action_decode(side_len: int, a: int) -> TaflPlay:
-    per = 4 * (side_len - 1)
-    sq, rem = divmod(a, per)
-    d, dist = divmod(rem, side_len - 1)
-    dist += 1
-    return TaflPlay(sq // side_len, sq % side_len, VERTICAL if d < 2 else HORIZONTAL, -dist if d & 1 else dist)
+    n, m = side_len, side_len - 1
+    sq, slot = divmod(a, 2 * m)
+    r, c = divmod(sq, n)
+    if slot < m - r:
+        return TaflPlay(r, c, VERTICAL, slot + 1)
+    if slot < m:
+        return TaflPlay(r, c, VERTICAL, -(slot - (m - r) + 1))
+    if slot < m + (m - c):
+        return TaflPlay(r, c, HORIZONTAL, slot - m + 1)
+    return TaflPlay(r, c, HORIZONTAL, -(slot - m - (m - c) + 1))

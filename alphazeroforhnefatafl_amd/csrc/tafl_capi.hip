@@ -300,22 +300,27 @@ int tafl_ctx_destroy(tafl_ctx* c) {
 
 void* tafl_ctx_stream(tafl_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-uint32_t tafl_action_size(const tafl_ctx* c) { return c ? c->n * c->n * 4u * (c->n - 1) : 0; }
+uint32_t tafl_action_size(const tafl_ctx* c) { return c ? c->n * c->n * 2u * (c->n - 1) : 0; }
 uint32_t tafl_action_mask_words(const tafl_ctx* c) { return (tafl_action_size(c) + 31) / 32; }
 int tafl_action_encode(const tafl_ctx* c, tafl_play p, uint32_t* action) {
     if (!c || !action) return fail(TAFL_ERR_INVALID_ARG, "null argument");
-    const uint32_t dist = (uint32_t)(p.disp < 0 ? -(int)p.disp : (int)p.disp);
-    if (p.from_row >= c->n || p.from_col >= c->n || dist == 0 || dist > c->n - 1) return fail(TAFL_ERR_INVALID_ARG, "play outside the action space");
-    const uint32_t dir = p.axis == TAFL_AXIS_VERTICAL ? (p.disp > 0 ? 0u : 1u) : (p.disp > 0 ? 2u : 3u);
-    *action = ((uint32_t)p.from_row * c->n + p.from_col) * 4u * (c->n - 1) + dir * (c->n - 1) + (dist - 1);
+    const uint32_t dist = (uint32_t)(p.disp < 0 ? -(int)p.disp : (int)p.disp), r = p.from_row, cc = p.from_col, m = c->n - 1;
+    if (r >= c->n || cc >= c->n || dist == 0) return fail(TAFL_ERR_INVALID_ARG, "play outside the action space");
+    const bool vert = p.axis == TAFL_AXIS_VERTICAL;
+    const uint32_t room = vert ? (p.disp > 0 ? m - r : r) : (p.disp > 0 ? m - cc : cc);
+    if (dist > room) return fail(TAFL_ERR_INVALID_ARG, "play outside the action space");
+    const uint32_t slot = vert ? (p.disp > 0 ? dist - 1 : (m - r) + dist - 1) : (p.disp > 0 ? m + dist - 1 : m + (m - cc) + dist - 1);
+    *action = (r * c->n + cc) * 2u * m + slot;
     return TAFL_OK;
 }
 int tafl_action_decode(const tafl_ctx* c, uint32_t a, tafl_play* play) {
     if (!c || !play || a >= tafl_action_size(c)) return fail(TAFL_ERR_INVALID_ARG, "action out of range");
-    const uint32_t per = 4u * (c->n - 1), sq = a / per, rem = a % per, dir = rem / (c->n - 1), dist = rem % (c->n - 1) + 1;
-    play->from_row = (uint8_t)(sq / c->n); play->from_col = (uint8_t)(sq % c->n);
-    play->axis = dir < 2 ? TAFL_AXIS_VERTICAL : TAFL_AXIS_HORIZONTAL;
-    play->disp = (int8_t)((dir & 1) ? -(int)dist : (int)dist);
+    const uint32_t m = c->n - 1, per = 2u * m, sq = a / per, slot = a % per, r = sq / c->n, cc = sq % c->n;
+    play->from_row = (uint8_t)r; play->from_col = (uint8_t)cc;
+    if (slot < m - r) { play->axis = TAFL_AXIS_VERTICAL; play->disp = (int8_t)(slot + 1); }
+    else if (slot < m) { play->axis = TAFL_AXIS_VERTICAL; play->disp = (int8_t)(-(int)(slot - (m - r) + 1)); }
+    else if (slot < m + (m - cc)) { play->axis = TAFL_AXIS_HORIZONTAL; play->disp = (int8_t)(slot - m + 1); }
+    else { play->axis = TAFL_AXIS_HORIZONTAL; play->disp = (int8_t)(-(int)(slot - m - (m - cc) + 1)); }
     return TAFL_OK;
 }
 
@@ -651,7 +656,7 @@ int tafl_mcts_policy(tafl_batch* b, double temp, double* out) {
 
 int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visits) {
     if (!b || !out_plays || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
-    const uint32_t n = b->n, mc = 4u * (b->ctx->n - 1) * 40u;
+    const uint32_t n = b->n, mc = 2u * (b->ctx->n - 1) * 40u;
     std::vector<tafl_root_child> kids((size_t)n * mc); std::vector<uint32_t> cnt(n);
     int rc = tafl_mcts_root_children(b, kids.data(), mc, cnt.data());
     if (rc) return rc;

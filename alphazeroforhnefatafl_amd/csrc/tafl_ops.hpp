@@ -111,9 +111,11 @@ struct Ops {
         p.disp = (int8_t)((m.dir & 1) ? -(int)m.dist : (int)m.dist);
         return p;
     }
+    // dense action index (include/taflhip.h): (from tile) * 2(n-1) + slot, slots ordered V+,V-,H+,H- by distance
     static TAFL_HD uint32_t action_of(const Move& m, const K& C) {
-        const uint32_t r = m.from / (uint32_t)W, c = m.from % (uint32_t)W;
-        return (r * C.n + c) * 4u * (C.n - 1) + m.dir * (C.n - 1) + (m.dist - 1);
+        const uint32_t r = m.from / (uint32_t)W, c = m.from % (uint32_t)W, nm = C.n - 1;
+        const uint32_t slot = m.dir == 0 ? m.dist - 1 : m.dir == 1 ? (nm - r) + m.dist - 1 : m.dir == 2 ? nm + m.dist - 1 : nm + (nm - c) + m.dist - 1;
+        return (r * C.n + c) * 2u * nm + slot;
     }
 
     // tafl_movegen: count + dense action mask (mask may be null; it must be zero-initialised by the caller)
@@ -129,7 +131,7 @@ struct Ops {
                     r = andn(r, bit_at<NL>(to));
                     const Move m = E::resolve(st, (uint32_t)d, to);
                     const uint32_t a = action_of(m, C);
-                    if (a < C.n * C.n * 4u * (C.n - 1)) mask[a >> 5] |= 1u << (a & 31);   // never write outside the game's mask
+                    if (a < C.n * C.n * 2u * (C.n - 1)) mask[a >> 5] |= 1u << (a & 31);   // never write outside the game's mask
                 }
             }
         }

@@ -228,11 +228,15 @@ int tafl_abi_version(void);
 int tafl_preset_rules(const char* name, tafl_rules* out);
 const char* tafl_preset_board(const char* name); /* start FEN, NULL if unknown; "copenhagen13" is build-defined */
 
-/* dense action space (the `getActionSize()` of src/mcts.py:41):
- * action = (from_row*side_len + from_col) * 4*(side_len-1) + dir*(side_len-1) + (dist-1),
- * dir: 0 = V+ (row+), 1 = V-, 2 = H+ (col+), 3 = H-  — the iteration order of
- * ValidPlayIterator (game/play.rs:157,166-183) over iter_occupied (game/board/state.rs:202-216),
- * i.e. ascending action index == get_all_possible_moves order (game/main.rs:33-43). */
+/* dense action space (the `getActionSize()` of src/mcts.py:41): side_len^2 * 2*(side_len-1) actions — every
+ * (from tile, destination on its row or column) pair.  For from = (r, c), n = side_len, dist >= 1:
+ *   action = (r*n + c) * 2*(n-1) + slot,   slot = V+ (row+): dist-1            [n-1-r slots]
+ *                                                 V- (row-): (n-1-r) + dist-1    [r slots]
+ *                                                 H+ (col+): (n-1) + dist-1      [n-1-c slots]
+ *                                                 H- (col-): (n-1) + (n-1-c) + dist-1   [c slots]
+ * i.e. the iteration order of ValidPlayIterator (game/play.rs:157,166-183: V+,V-,H+,H-, distance ascending) over
+ * iter_occupied (game/board/state.rs:202-216, row-major), so ascending action index == get_all_possible_moves
+ * order (game/main.rs:33-43).  Dense mask: 2420 bits = 76 uint32 words for 11x11 (SURVEY.md §8d, M = 304 B). */
 uint32_t tafl_action_size(const tafl_ctx* ctx);
 uint32_t tafl_action_mask_words(const tafl_ctx* ctx);  /* uint32 words per game in a dense mask */
 int tafl_action_encode(const tafl_ctx* ctx, tafl_play play, uint32_t* action);
