@@ -42,6 +42,14 @@ template <int NL> TAFL_HD uint32_t popc(const Bits<NL>& a) { uint32_t c = 0; TAF
 template <int NL> TAFL_HD Bits<NL> gate(const Bits<NL>& a, bool cond) { uint32_t m = cond ? 0xFFFFFFFFu : 0u; Bits<NL> o; TAFL_UNROLL for (int i = 0; i < NL; ++i) o.w[i] = a.w[i] & m; return o; }
 template <int NL> TAFL_HD Bits<NL> sel(bool cond, const Bits<NL>& a, const Bits<NL>& b) { Bits<NL> o; TAFL_UNROLL for (int i = 0; i < NL; ++i) o.w[i] = cond ? a.w[i] : b.w[i]; return o; }
 
+// (cond ? a : b) by mask arithmetic: keeps constant operands as literals (a select of two constant objects is
+// otherwise lowered to a pointer select + memory load)
+template <int NL> TAFL_HD Bits<NL> blend(bool cond, const Bits<NL>& a, const Bits<NL>& b) {
+    const uint32_t m = cond ? 0xFFFFFFFFu : 0u; Bits<NL> o;
+    TAFL_UNROLL for (int i = 0; i < NL; ++i) o.w[i] = (a.w[i] & m) | (b.w[i] & ~m);
+    return o;
+}
+
 // compile-time shifts (funnel shifts: v_alignbit_b32 on gfx950)
 template <int K, int NL>
 TAFL_HD Bits<NL> shl(const Bits<NL>& a) {
@@ -122,17 +130,17 @@ TAFL_HD uint32_t nth_set_bit32(uint32_t v, uint32_t j) {
     }
     return pos;
 }
-// index of the j-th (0-based) set bit, j < popc(a)
+// index of the j-th (0-based) set bit, j < popc(a).  Mask arithmetic only: a select chain here gets turned into a
+// scratch-backed indexed load by the compiler.
 template <int NL> TAFL_HD uint32_t nth_set_bit(const Bits<NL>& a, uint32_t j) {
-    uint32_t word = 0, base = 0; bool found = false;
+    uint32_t word = 0, base = 0, rem = 0, acc = 0;
     TAFL_UNROLL for (int i = 0; i < NL; ++i) {
         const uint32_t c = (uint32_t)__builtin_popcount(a.w[i]);
-        if (!found) {
-            if (j < c) { word = a.w[i]; base = (uint32_t)i * 32u; found = true; }
-            else j -= c;
-        }
+        const uint32_t hit = (j >= acc && j < acc + c) ? 0xFFFFFFFFu : 0u;      // at most one word hits
+        word |= a.w[i] & hit; base |= ((uint32_t)i * 32u) & hit; rem |= (j - acc) & hit;
+        acc += c;
     }
-    return base + nth_set_bit32(word, j);
+    return base + nth_set_bit32(word, rem);
 }
 
 }  // namespace tafl

@@ -81,21 +81,29 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_side_can_play(Consts<NL> C, cons
     out[g] = Ops<NL, W>::side_can_play(st, side, C) ? 1 : 0;
 }
 
-template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_rollout(Consts<NL> C, const Quad* soa, uint32_t n, uint64_t seed, uint32_t sim, uint32_t max_plies,
+// For PRESET != 0 every geometry / rule mask is a compile-time literal (no SMEM loads, no SGPR pressure) and rule
+// branches that the preset never takes are pruned; PRESET == 0 uses the run-time Consts passed as a kernel argument.
+#define TAFL_PICK_CONSTS(C, Carg)                                                   \
+    constexpr Consts<NL> C##_ct = preset_consts<NL, W, PRESET>();                   \
+    const Consts<NL>& C = (PRESET != PRESET_NONE) ? C##_ct : (Carg)
+
+template <int NL, int W, int PRESET>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_rollout(Consts<NL> Carg, const Quad* soa, uint32_t n, uint64_t seed, uint32_t sim, uint32_t max_plies,
                                                         uint64_t base, tafl_rollout_result* out) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= n) return;
+    TAFL_PICK_CONSTS(C, Carg);
     DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
     tafl_rollout_result r;
     Ops<NL, W>::rollout(st, seed, base + g, sim, max_plies, C, r);
     out[g] = r;
 }
 
-template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_random_advance(Consts<NL> C, Quad* soa, uint32_t n, uint64_t seed, const uint32_t* plies, uint64_t base) {
+template <int NL, int W, int PRESET>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_random_advance(Consts<NL> Carg, Quad* soa, uint32_t n, uint64_t seed, const uint32_t* plies, uint64_t base) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= n) return;
+    TAFL_PICK_CONSTS(C, Carg);
     DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
     Ops<NL, W>::random_advance(st, seed, base + g, plies[g], C);
     StateIO<NL>::store_soa(soa, n, g, st);
@@ -122,9 +130,10 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_init(Consts<NL> C, const Qu
 }
 
 // backup of simulation i-1 fused with select/expand of simulation i (both walk the same tree arena)
-template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> C, MctsMem M, double c_puct, int do_backup, int do_select, unsigned long long* stats) {
+template <int NL, int W, int PRESET>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, int do_backup, int do_select, unsigned long long* stats) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    TAFL_PICK_CONSTS(C, Carg);
     LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
     if (g < M.G) {
         if (do_backup) Ops<NL, W>::mcts_backup(M, g);
@@ -135,10 +144,11 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> C, MctsMem 
 }
 
 // the dominant kernel: one seeded random playout per game, state resident in registers
-template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_rollout(Consts<NL> C, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim, uint32_t max_plies,
+template <int NL, int W, int PRESET>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim, uint32_t max_plies,
                                                              unsigned long long* stats) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    TAFL_PICK_CONSTS(C, Carg);
     LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
     if (g < M.G) Ops<NL, W>::mcts_rollout(M, g, seed, base + g, sim, max_plies, C, ls);
     stat_add(stats, ST_ROLLOUTS, ls.rollouts); stat_add(stats, ST_PLIES, ls.rollout_plies);
@@ -188,6 +198,7 @@ struct tafl_ctx {
     hipStream_t stream;
     bool own_stream;
     Consts<2> c2; Consts<4> c4; Consts<8> c8;
+    int preset;                      // PRESET_* detected at ctx_create: selects kernels with compile-time constants
     bool timing;
     std::vector<TimedSpan> spans;
     double acc_ms[KC_COUNT]; uint64_t acc_n[KC_COUNT];
@@ -224,6 +235,17 @@ static uint32_t grid_of(uint32_t n) { return (n + TAFL_BLOCK - 1) / TAFL_BLOCK; 
         if ((ctx)->nl == 2) { constexpr int NL = 2, W = 7; const Consts<2>& CC = (ctx)->c2; (void)CC; (void)W; STMT; }        \
         else if ((ctx)->nl == 4) { constexpr int NL = 4, W = 11; const Consts<4>& CC = (ctx)->c4; (void)CC; (void)W; STMT; }  \
         else { constexpr int NL = 8, W = 15; const Consts<8>& CC = (ctx)->c8; (void)CC; (void)W; STMT; }                      \
+    } while (0)
+
+// same, for the hot kernels that also exist specialised on a compile-time preset
+#define DISPATCH_PRESET(ctx, STMT)                                                                                        \
+    do {                                                                                                                  \
+        if ((ctx)->nl == 2) { constexpr int NL = 2, W = 7; const Consts<2>& CC = (ctx)->c2; (void)CC; (void)W;            \
+            if ((ctx)->preset == PRESET_BRANDUBH7) { constexpr int PRESET = PRESET_BRANDUBH7; STMT; } else { constexpr int PRESET = PRESET_NONE; STMT; } } \
+        else if ((ctx)->nl == 4) { constexpr int NL = 4, W = 11; const Consts<4>& CC = (ctx)->c4; (void)CC; (void)W;      \
+            if ((ctx)->preset == PRESET_COPENHAGEN11) { constexpr int PRESET = PRESET_COPENHAGEN11; STMT; } else { constexpr int PRESET = PRESET_NONE; STMT; } } \
+        else { constexpr int NL = 8, W = 15; const Consts<8>& CC = (ctx)->c8; (void)CC; (void)W;                          \
+            if ((ctx)->preset == PRESET_COPENHAGEN13) { constexpr int PRESET = PRESET_COPENHAGEN13; STMT; } else { constexpr int PRESET = PRESET_NONE; STMT; } } \
     } while (0)
 
 struct SpanGuard {
@@ -277,6 +299,7 @@ int tafl_ctx_create(const tafl_rules* rules, uint8_t side_len, uint32_t word_bit
     if (!c) return fail(TAFL_ERR_OOM, "out of host memory");
     c->rules = *rules; c->n = side_len; c->word_bits = word_bits; c->nl = (uint32_t)l64 * 2; c->w = (uint32_t)rw; c->device = device;
     c->timing = false;
+    c->preset = getenv("TAFL_NO_PRESET") ? PRESET_NONE : detect_preset(*rules, side_len, word_bits);
     for (int i = 0; i < KC_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
     int rc = 0;
     if (c->nl == 2) rc = make_consts<2, 7>(*rules, side_len, c->c2);
@@ -512,7 +535,7 @@ int tafl_rollout(tafl_batch* b, uint64_t seed, uint32_t sim, uint32_t max_plies,
     NEED(b->results, sizeof(tafl_rollout_result) * n);
     {
         SpanGuard sg(c, KC_ROLLOUT);
-        DISPATCH_NLW(c, hipLaunchKernelGGL((k_rollout<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, seed, sim, max_plies,
+        DISPATCH_PRESET(c, hipLaunchKernelGGL((k_rollout<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, seed, sim, max_plies,
                                            game_id_base, (tafl_rollout_result*)b->results.p));
     }
     HIPCHK(hipGetLastError());
@@ -527,7 +550,7 @@ int tafl_random_advance(tafl_batch* b, uint64_t seed, const uint32_t* plies, uin
     HIPCHK(hipSetDevice(c->device));
     NEED(b->plies, sizeof(uint32_t) * n);
     HIPCHK(hipMemcpyAsync(b->plies.p, plies, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_random_advance<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, seed,
+    DISPATCH_PRESET(c, hipLaunchKernelGGL((k_random_advance<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, seed,
                                        (const uint32_t*)b->plies.p, game_id_base));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -571,17 +594,17 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     for (uint32_t i = 0; i < p->n_sims; ++i) {
         {
             SpanGuard sg(c, KC_MCTS_TREE);
-            DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_tree<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, i > 0 ? 1 : 0, 1, st));
+            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, i > 0 ? 1 : 0, 1, st));
         }
         {
             SpanGuard sg(c, KC_MCTS_ROLLOUT);
-            DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->seed, game_id_base,
+            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->seed, game_id_base,
                                                p->sim_offset + i, p->max_rollout_plies, st));
         }
     }
     {
         SpanGuard sg(c, KC_MCTS_BACKUP);
-        DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_tree<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, 1, 0, st));
+        DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, 1, 0, st));
     }
     HIPCHK(hipGetLastError());
     b->ran = true;

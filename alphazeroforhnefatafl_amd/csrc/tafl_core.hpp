@@ -409,10 +409,12 @@ struct Engine {
             // hostile-to-victim occupied tiles: mover-side pieces, an unarmed king excluded (tile_hostile :85-93)
             B friends = (mover ? st.def : st.att) & C.board;
             if (mover && !king_armed_as_anvil(C)) friends = andn(friends, kb);
-            const int vcls = mover ? CLS_ATT : CLS_DEF;
+            // victim class = the other side's soldiers; constants picked with selects (a run-time array index into the
+            // constants would become a memory load inside the playout loop)
             const B victims = mover ? (st.att & C.board) : andn(st.def & C.board, kb);   // enemy soldiers
-            const B hostile = friends | (empty & C.hostile_special[vcls]);
-            const bool eh = C.edge_hostile[vcls] != 0;
+            const B hostile = friends | (empty & blend(mover != 0, C.hostile_special[CLS_ATT], C.hostile_special[CLS_DEF]));
+            const uint32_t mm = mover ? 0xFFFFFFFFu : 0u;
+            const bool eh = ((C.edge_hostile[CLS_ATT] & mm) | (C.edge_hostile[CLS_DEF] & ~mm)) != 0;
             B cs = custodial_dir<DIR_VP>(tbit, victims, hostile, eh, C) | custodial_dir<DIR_VM>(tbit, victims, hostile, eh, C)
                  | custodial_dir<DIR_HP>(tbit, victims, hostile, eh, C) | custodial_dir<DIR_HM>(tbit, victims, hostile, eh, C);
             // Linnaean capture (logic.rs:676-685, :859-879): only for victims whose far tile was not hostile
@@ -591,47 +593,99 @@ struct Engine {
     }
 };
 
-// ---- host-side construction of Consts (pure integer set-up; runs on the CPU in both builds) ----------------------
+// ---- construction of Consts: constexpr, so that kernels specialised for a preset get every mask as a literal ------
 template <int NL, int W>
-inline int make_consts(const tafl_rules& r, uint32_t n, Consts<NL>& C) {
-    if (n < 3 || n > (uint32_t)W || n > 15) return -1;
-    auto setb = [](Bits<NL>& b, uint32_t idx) { b.w[idx >> 5] |= 1u << (idx & 31); };
-    auto zero = [](Bits<NL>& b) { for (int i = 0; i < NL; ++i) b.w[i] = 0; };
-    zero(C.board); zero(C.col0); zero(C.coln); zero(C.row0); zero(C.rown); zero(C.edge); zero(C.corners); zero(C.throne); zero(C.throne_nb);
+constexpr Consts<NL> make_consts_ct(const tafl_rules& r, uint32_t n) {
+    Consts<NL> C{};
     for (uint32_t rr = 0; rr < n; ++rr) for (uint32_t cc = 0; cc < n; ++cc) {
-        const uint32_t i = rr * (uint32_t)W + cc;
-        setb(C.board, i);
-        if (cc == 0) setb(C.col0, i);
-        if (cc == n - 1) setb(C.coln, i);
-        if (rr == 0) setb(C.row0, i);
-        if (rr == n - 1) setb(C.rown, i);
-        if (cc == 0 || rr == 0 || cc == n - 1 || rr == n - 1) setb(C.edge, i);
-        if ((rr == 0 || rr == n - 1) && (cc == 0 || cc == n - 1)) setb(C.corners, i);
+        const uint32_t i = rr * (uint32_t)W + cc; const uint32_t wi = i >> 5, b = 1u << (i & 31);
+        C.board.w[wi] |= b;
+        if (cc == 0) C.col0.w[wi] |= b;
+        if (cc == n - 1) C.coln.w[wi] |= b;
+        if (rr == 0) C.row0.w[wi] |= b;
+        if (rr == n - 1) C.rown.w[wi] |= b;
+        if (cc == 0 || rr == 0 || cc == n - 1 || rr == n - 1) C.edge.w[wi] |= b;
+        if ((rr == 0 || rr == n - 1) && (cc == 0 || cc == n - 1)) C.corners.w[wi] |= b;
     }
     const uint32_t t = n / 2;                                         // SpecialTiles::from, geometry.rs:13-25
-    C.throne_sq = t * (uint32_t)W + t; setb(C.throne, C.throne_sq);
-    if (t >= 1) { setb(C.throne_nb, (t - 1) * W + t); setb(C.throne_nb, t * W + t - 1); }
-    if (t + 1 < n) { setb(C.throne_nb, (t + 1) * W + t); setb(C.throne_nb, t * W + t + 1); }
+    C.throne_sq = t * (uint32_t)W + t;
+    C.throne.w[C.throne_sq >> 5] |= 1u << (C.throne_sq & 31);
+    const uint32_t nb[4] = {(t - 1) * W + t, t * W + t - 1, (t + 1) * W + t, t * W + t + 1};
+    const bool nbok[4] = {t >= 1, t >= 1, t + 1 < n, t + 1 < n};
+    for (int k = 0; k < 4; ++k) if (nbok[k]) C.throne_nb.w[nb[k] >> 5] |= 1u << (nb[k] & 31);
     C.n = n; C.w = (uint32_t)W; C.rules = r;
     const uint32_t psbit[3] = {1u /*Soldier<<0*/, 9u /*Soldier<<8*/, 8u /*King<<8*/};
     for (int c = 0; c < 3; ++c) {
         const bool is_king = c == CLS_KING;
-        auto has = [&](uint16_t set) { return ((set >> psbit[c]) & 1u) != 0; };
-        zero(C.land_forbid[c]); zero(C.pass_forbid[c]); zero(C.hostile_special[c]);
-        if (!has(r.may_enter_corners)) for (int i = 0; i < NL; ++i) { C.land_forbid[c].w[i] |= C.corners.w[i]; C.pass_forbid[c].w[i] |= C.corners.w[i]; }
-        if (r.throne_movement == TAFL_THRONE_NOENTRY || (r.throne_movement == TAFL_THRONE_KINGENTRY && !is_king))
-            for (int i = 0; i < NL; ++i) C.land_forbid[c].w[i] |= C.throne.w[i];
-        if (r.throne_movement == TAFL_THRONE_NOPASS || (r.throne_movement == TAFL_THRONE_KINGPASS && !is_king))
-            for (int i = 0; i < NL; ++i) C.pass_forbid[c].w[i] |= C.throne.w[i];
-        if (has(r.hostility_throne)) for (int i = 0; i < NL; ++i) C.hostile_special[c].w[i] |= C.throne.w[i];
-        if (has(r.hostility_corners)) for (int i = 0; i < NL; ++i) C.hostile_special[c].w[i] |= C.corners.w[i];
-        C.slow[c] = has(r.slow_pieces) ? 1u : 0u;
-        C.edge_hostile[c] = has(r.hostility_edge) ? 1u : 0u;
+        const bool enter = ((r.may_enter_corners >> psbit[c]) & 1u) != 0;
+        const bool hthr = ((r.hostility_throne >> psbit[c]) & 1u) != 0, hcor = ((r.hostility_corners >> psbit[c]) & 1u) != 0;
+        const bool no_land_throne = r.throne_movement == TAFL_THRONE_NOENTRY || (r.throne_movement == TAFL_THRONE_KINGENTRY && !is_king);
+        const bool no_pass_throne = r.throne_movement == TAFL_THRONE_NOPASS || (r.throne_movement == TAFL_THRONE_KINGPASS && !is_king);
+        for (int i = 0; i < NL; ++i) {
+            uint32_t lf = 0, pf = 0, hs = 0;
+            if (!enter) { lf |= C.corners.w[i]; pf |= C.corners.w[i]; }
+            if (no_land_throne) lf |= C.throne.w[i];
+            if (no_pass_throne) pf |= C.throne.w[i];
+            if (hthr) hs |= C.throne.w[i];
+            if (hcor) hs |= C.corners.w[i];
+            C.land_forbid[c].w[i] = lf; C.pass_forbid[c].w[i] = pf; C.hostile_special[c].w[i] = hs;
+        }
+        C.slow[c] = ((r.slow_pieces >> psbit[c]) & 1u) ? 1u : 0u;
+        C.edge_hostile[c] = ((r.hostility_edge >> psbit[c]) & 1u) ? 1u : 0u;
     }
     bool same = C.slow[CLS_KING] == C.slow[CLS_DEF];
     for (int i = 0; i < NL; ++i) same = same && C.land_forbid[CLS_KING].w[i] == C.land_forbid[CLS_DEF].w[i] && C.pass_forbid[CLS_KING].w[i] == C.pass_forbid[CLS_DEF].w[i];
     C.king_like_soldier = same ? 1u : 0u;
+    return C;
+}
+template <int NL, int W>
+inline int make_consts(const tafl_rules& r, uint32_t n, Consts<NL>& C) {
+    if (n < 3 || n > (uint32_t)W || n > 15) return -1;
+    C = make_consts_ct<NL, W>(r, n);
     return 0;
+}
+
+// ---- presets known at compile time (game/preset.rs:12-56): kernels specialised on these fold all rule tests -------
+constexpr tafl_rules rules_copenhagen_ct() {
+    tafl_rules r{};
+    r.king_strength = TAFL_KING_STRONG; r.king_attack = TAFL_KING_ARMED; r.has_shieldwall = 1; r.sw_corners_may_close = 1;
+    r.sw_captures = TAFL_PS_TYPE(TAFL_PT_SOLDIER); r.exit_fort = 1; r.throne_movement = TAFL_THRONE_KINGENTRY;
+    r.may_enter_corners = TAFL_PS_TYPE(TAFL_PT_KING); r.hostility_throne = TAFL_PS_ALL; r.hostility_corners = TAFL_PS_TYPE(TAFL_PT_SOLDIER);
+    r.starting_side = TAFL_ATTACKER; r.enclosure_win = TAFL_ENCL_WITHOUT_EDGE_ACCESS; r.has_repetition_rule = 1; r.n_repetitions = 3; r.rep_is_loss = 1;
+    return r;
+}
+constexpr tafl_rules rules_brandubh_ct() {
+    tafl_rules r{};
+    r.king_strength = TAFL_KING_STRONG_BY_THRONE; r.king_attack = TAFL_KING_ARMED; r.throne_movement = TAFL_THRONE_KINGENTRY;
+    r.may_enter_corners = TAFL_PS_TYPE(TAFL_PT_KING); r.hostility_throne = TAFL_PS_TYPE(TAFL_PT_SOLDIER); r.hostility_corners = TAFL_PS_ALL;
+    r.starting_side = TAFL_ATTACKER; r.enclosure_win = TAFL_ENCL_WITHOUT_EDGE_ACCESS; r.has_repetition_rule = 1; r.n_repetitions = 3; r.rep_is_loss = 1;
+    return r;
+}
+// PRESET: 0 = run-time rules (Consts passed as a kernel argument), 1 = Copenhagen 11x11 / u128, 2 = Brandubh 7x7 / u64,
+//         3 = Copenhagen 13x13 / U256
+enum : int { PRESET_NONE = 0, PRESET_COPENHAGEN11 = 1, PRESET_BRANDUBH7 = 2, PRESET_COPENHAGEN13 = 3 };
+template <int NL, int W, int PRESET>
+constexpr Consts<NL> preset_consts() {
+    if constexpr (PRESET == PRESET_COPENHAGEN11 && NL == 4 && W == 11) return make_consts_ct<NL, W>(rules_copenhagen_ct(), 11);
+    else if constexpr (PRESET == PRESET_BRANDUBH7 && NL == 2 && W == 7) return make_consts_ct<NL, W>(rules_brandubh_ct(), 7);
+    else if constexpr (PRESET == PRESET_COPENHAGEN13 && NL == 8 && W == 15) return make_consts_ct<NL, W>(rules_copenhagen_ct(), 13);
+    else return Consts<NL>{};
+}
+inline bool rules_equal(const tafl_rules& a, const tafl_rules& b) {
+    return a.edge_escape == b.edge_escape && a.king_strength == b.king_strength && a.king_attack == b.king_attack
+        && a.has_shieldwall == b.has_shieldwall && (!a.has_shieldwall || (a.sw_corners_may_close == b.sw_corners_may_close && a.sw_captures == b.sw_captures))
+        && a.exit_fort == b.exit_fort && a.throne_movement == b.throne_movement && a.starting_side == b.starting_side
+        && a.enclosure_win == b.enclosure_win && a.has_repetition_rule == b.has_repetition_rule
+        && (!a.has_repetition_rule || (a.rep_is_loss == b.rep_is_loss && a.n_repetitions == b.n_repetitions))
+        && a.draw_on_no_plays == b.draw_on_no_plays && a.linnaean_capture == b.linnaean_capture
+        && a.may_enter_corners == b.may_enter_corners && a.hostility_throne == b.hostility_throne
+        && a.hostility_corners == b.hostility_corners && a.hostility_edge == b.hostility_edge && a.slow_pieces == b.slow_pieces;
+}
+inline int detect_preset(const tafl_rules& r, uint32_t n, uint32_t word_bits) {
+    if (n == 11 && word_bits == 128 && rules_equal(r, rules_copenhagen_ct())) return PRESET_COPENHAGEN11;
+    if (n == 7 && word_bits == 64 && rules_equal(r, rules_brandubh_ct())) return PRESET_BRANDUBH7;
+    if (n == 13 && word_bits == 256 && rules_equal(r, rules_copenhagen_ct())) return PRESET_COPENHAGEN13;
+    return PRESET_NONE;
 }
 
 // ---- ABI <-> device state conversion (host side) -------------------------------------------------------------------------
