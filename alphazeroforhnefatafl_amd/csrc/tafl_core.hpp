@@ -173,13 +173,33 @@ struct Engine {
         Move m; m.from = (uint32_t)sq; m.to = to; m.dir = dir; m.dist = dist;
         return m;
     }
-    // idx-th play in ROLLOUT ORDER = (direction, destination tile ascending)  [build-defined, DESIGN.md]
-    static TAFL_HD Move pick_rollout(const S& st, const Moves<NL>& mv, uint32_t idx) {
-        uint32_t dir = 0; B r = mv.reach[0];
-        if (idx >= mv.cnt[0]) { idx -= mv.cnt[0]; dir = 1; r = mv.reach[1];
-            if (idx >= mv.cnt[1]) { idx -= mv.cnt[1]; dir = 2; r = mv.reach[2];
-                if (idx >= mv.cnt[2]) { idx -= mv.cnt[2]; dir = 3; r = mv.reach[3]; } } }
-        return resolve(st, dir, nth_set_bit(r, idx));
+    // idx-th play in ROLLOUT ORDER [build-defined, DESIGN.md]: direction-major V+,V-,H+,H-; inside a direction the
+    // destinations in the natural order of the layout where that direction is "+1": V+ ascending (col,row), V- descending
+    // (col,row), H+ ascending (row,col), H- descending (row,col).  This generic version works from the row-major sets;
+    // the fast playout engine (tafl_fast.hpp) produces the same order directly from its four layouts.
+    static TAFL_HD uint32_t nth_colmajor(const B& r, uint32_t j, const K& C) {
+        uint32_t res = 0; bool found = false;
+        for (uint32_t c = 0; c < C.n; ++c) {
+            B colm = bz<NL>();
+            // column c = col0 pattern moved right by c (c < W <= 15: at most one limb of carry)
+            TAFL_UNROLL for (int i = 0; i < NL; ++i) colm.w[i] = (C.col0.w[i] << c) | ((c && i > 0) ? (C.col0.w[i - 1] >> (32 - c)) : 0u);
+            const B rc = r & colm;
+            const uint32_t k = popc(rc);
+            if (!found) { if (j < k) { res = nth_set_bit(rc, j); found = true; } else j -= k; }
+        }
+        return res;
+    }
+    static TAFL_HD Move pick_rollout(const S& st, const Moves<NL>& mv, uint32_t idx, const K& C) {
+        uint32_t dir = 0;
+        if (idx >= mv.cnt[0]) { idx -= mv.cnt[0]; dir = 1;
+            if (idx >= mv.cnt[1]) { idx -= mv.cnt[1]; dir = 2;
+                if (idx >= mv.cnt[2]) { idx -= mv.cnt[2]; dir = 3; } } }
+        uint32_t to;
+        if (dir == 0) to = nth_colmajor(mv.reach[0], idx, C);
+        else if (dir == 1) to = nth_colmajor(mv.reach[1], mv.cnt[1] - 1 - idx, C);
+        else if (dir == 2) to = nth_set_bit(mv.reach[2], idx);
+        else to = nth_set_bit(mv.reach[3], mv.cnt[3] - 1 - idx);
+        return resolve(st, dir, to);
     }
 
     // ---- canonical iteration (ValidPlayIterator order: play.rs:157,166-183 over iter_occupied) -------------
@@ -576,7 +596,7 @@ struct Engine {
         while (ply < max_plies && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
             if (mv.total == 0) { stuck = true; break; }
             const uint32_t idx = mulhi(ply_rand(sk, ply), mv.total);
-            const Move m = pick_rollout(st, mv, idx);
+            const Move m = pick_rollout(st, mv, idx, C);
             Moves<NL> nx;
             apply(st, m, C, nullptr, nx);
             mv = nx;
