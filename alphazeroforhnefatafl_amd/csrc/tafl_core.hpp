@@ -509,8 +509,14 @@ struct Engine {
     }
 
     // ---- do_valid_play (logic.rs:782-820) + get_game_outcome (:702-771) ---------------------------------------------
-    // `next` receives the opponent's move set (computed for the NoPlays test, reused by rollouts).
-    static TAFL_HD void apply(S& st, const Move& m, const K& C, StepOut<NL>* out, Moves<NL>& next) {
+    // Split in three so that the fast playout engine (tafl_fast.hpp) can slot its own move generator in between:
+    //   apply_pre      move the piece, captures, removal, repetition tracker             (logic.rs:787-799)
+    //   outcome_early  every outcome test that precedes the no-plays test              (logic.rs:709-758)
+    //   apply_finish   no-plays test from the opponent's move count, turn/side/status  (logic.rs:760-816)
+    struct ApplyCtx { uint32_t mover; bool mover_is_king, king_captured; B tbit, caps; uint32_t ncap; };
+    struct Outcome { bool over; uint32_t status, reason, winner; };
+
+    static TAFL_HD void apply_pre(S& st, const Move& m, const K& C, ApplyCtx& ax) {
         const uint32_t mover = st.flags & TAFL_F_SIDE;
         const B fbit = bit_at<NL>(m.from), tbit = bit_at<NL>(m.to);
         const bool mover_is_king = mover && m.from == king_sq(st, C);
@@ -523,58 +529,71 @@ struct Engine {
             }
         } else { st.att = andn(st.att, fbit) | tbit; st.def = andn(st.def, tbit); }
         const B caps = captures(st, m, mover, mover_is_king, C);
-        const bool king_captured_tile = mover == 0 && king_sq(st, C) != TAFL_NO_SQ && test(caps, king_sq(st, C));
+        ax.king_captured = mover == 0 && king_sq(st, C) != TAFL_NO_SQ && test(caps, king_sq(st, C));
         st.att = andn(st.att, caps); st.def = andn(st.def, caps);
-        const uint32_t ncap = popc(caps);
-        if (out) { out->captures = caps; out->n_captures = ncap; }
-        track(st, mover, m, ncap != 0);
-        if (ncap == 0) st.psc += 1;
-        // outcome
-        uint32_t status = TAFL_STATUS_ONGOING, reason = 0, winner = 0;
+        ax.ncap = popc(caps); ax.caps = caps; ax.mover = mover; ax.mover_is_king = mover_is_king; ax.tbit = tbit;
+        track(st, mover, m, ax.ncap != 0);
+        if (ax.ncap == 0) st.psc += 1;
+    }
+    // skip_enclosure: the caller has PROVED that the enclosure win cannot apply (see tafl_fast.hpp); never set otherwise.
+    static TAFL_HD Outcome outcome_early(const S& st, const ApplyCtx& ax, const K& C, bool skip_enclosure) {
+        Outcome o; o.over = false; o.status = TAFL_STATUS_ONGOING; o.reason = 0; o.winner = 0;
+        const uint32_t mover = ax.mover;
         const B other = (mover ? st.att : st.def) & C.board;
-        bool over = false;
-        if (!any(other)) { status = TAFL_STATUS_WIN; reason = TAFL_WIN_ALL_CAPTURED; winner = mover; over = true; }
-        if (!over && mover == 0) {
-            if (king_captured_tile) { status = TAFL_STATUS_WIN; reason = TAFL_WIN_KING_CAPTURED; winner = 0; over = true; }
-            else if (C.rules.enclosure_win != TAFL_ENCL_NONE) {
+        if (!any(other)) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_ALL_CAPTURED; o.winner = mover; o.over = true; }
+        if (!o.over && mover == 0) {
+            if (ax.king_captured) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_KING_CAPTURED; o.winner = 0; o.over = true; }
+            else if (C.rules.enclosure_win != TAFL_ENCL_NONE && !skip_enclosure) {
                 B fill;
                 const B inside = andn(C.board, st.att);
                 if (flood(king_sq(st, C), inside, bz<NL>(), C.rules.enclosure_win == TAFL_ENCL_WITHOUT_EDGE_ACCESS, true, C, fill)) {
                     if (popc(fill & st.def) == popc(st.def & C.board)) {
                         const B boundary = dilate(fill, C) & st.att;
                         if (secure(st, fill, boundary, CLS_ATT, false, true, C)) {
-                            status = TAFL_STATUS_WIN; reason = TAFL_WIN_ENCLOSED; winner = 0; over = true;
+                            o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_ENCLOSED; o.winner = 0; o.over = true;
                         }
                     }
                 }
             }
-        } else if (!over) {
-            if (mover_is_king && any(tbit & (C.rules.edge_escape ? C.edge : C.corners))) {
-                status = TAFL_STATUS_WIN; reason = TAFL_WIN_KING_ESCAPED; winner = 1; over = true;
+        } else if (!o.over) {
+            if (ax.mover_is_king && any(ax.tbit & (C.rules.edge_escape ? C.edge : C.corners))) {
+                o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_KING_ESCAPED; o.winner = 1; o.over = true;
             } else if (C.rules.exit_fort && exit_fort(st, C)) {
-                status = TAFL_STATUS_WIN; reason = TAFL_WIN_EXIT_FORT; winner = 1; over = true;
+                o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_EXIT_FORT; o.winner = 1; o.over = true;
             }
         }
-        if (!over && C.rules.has_repetition_rule) {
+        if (!o.over && C.rules.has_repetition_rule) {
             const uint32_t reps = mover ? (st.reps >> 16) : (st.reps & 0xFFFFu);
             if (reps >= C.rules.n_repetitions) {
-                if (C.rules.rep_is_loss) { status = TAFL_STATUS_WIN; reason = TAFL_WIN_REPETITION; winner = mover ^ 1u; }
-                else { status = TAFL_STATUS_DRAW; reason = TAFL_DRAW_REPETITION; }
-                over = true;
+                if (C.rules.rep_is_loss) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_REPETITION; o.winner = mover ^ 1u; }
+                else { o.status = TAFL_STATUS_DRAW; o.reason = TAFL_DRAW_REPETITION; }
+                o.over = true;
             }
         }
-        // side_can_play(other) (logic.rs:760-768, :837-846): status is still Ongoing while it is evaluated
-        if (!over) {
-            movegen(st, mover ^ 1u, C, next);
-            if (next.total == 0) {
-                if (C.rules.draw_on_no_plays) { status = TAFL_STATUS_DRAW; reason = TAFL_DRAW_NO_PLAYS; }
-                else { status = TAFL_STATUS_WIN; reason = TAFL_WIN_NO_PLAYS; winner = mover; }
-                over = true;
-            }
+        return o;
+    }
+    // next_total: number of plays of the opponent on the post-move board (side_can_play, logic.rs:760-768, :837-846)
+    static TAFL_HD void apply_finish(S& st, const ApplyCtx& ax, Outcome o, uint32_t next_total, const K& C) {
+        const uint32_t mover = ax.mover;
+        if (!o.over && next_total == 0) {
+            if (C.rules.draw_on_no_plays) { o.status = TAFL_STATUS_DRAW; o.reason = TAFL_DRAW_NO_PLAYS; }
+            else { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_NO_PLAYS; o.winner = mover; }
+            o.over = true;
         }
-        if (over) { TAFL_UNROLL for (int d = 0; d < 4; ++d) { next.reach[d] = bz<NL>(); next.cnt[d] = 0; } next.total = 0; }
         st.turn += 1;
-        st.flags = (st.flags & ~(TAFL_F_SIDE | (0x7Fu << 3))) | (mover ^ 1u) | (status << 3) | (reason << 5) | (winner << 9);
+        st.flags = (st.flags & ~(TAFL_F_SIDE | (0x7Fu << 3))) | (mover ^ 1u) | (o.status << 3) | (o.reason << 5) | (o.winner << 9);
+    }
+    // `next` receives the opponent's move set (computed for the NoPlays test, reused by rollouts).
+    static TAFL_HD void apply(S& st, const Move& m, const K& C, StepOut<NL>* out, Moves<NL>& next) {
+        ApplyCtx ax;
+        apply_pre(st, m, C, ax);
+        if (out) { out->captures = ax.caps; out->n_captures = ax.ncap; }
+        const Outcome o = outcome_early(st, ax, C, false);
+        // side_can_play(other): status is still Ongoing while it is evaluated
+        if (!o.over) movegen(st, ax.mover ^ 1u, C, next);
+        else { TAFL_UNROLL for (int d = 0; d < 4; ++d) { next.reach[d] = bz<NL>(); next.cnt[d] = 0; } next.total = 0; }
+        apply_finish(st, ax, o, o.over ? 1u : next.total, C);
+        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) { TAFL_UNROLL for (int d = 0; d < 4; ++d) { next.reach[d] = bz<NL>(); next.cnt[d] = 0; } next.total = 0; }
     }
 
     // ---- taflmix32 RNG (build-defined) -----------------------------------------------------------------------

@@ -1,0 +1,196 @@
+// tafl_fast.hpp — the playout (random rollout) engine: same results as Engine::rollout, far fewer instructions.
+//
+// Idea: a rook ray in the "+1" bit direction of a packed board falls out of ONE multi-word subtraction
+//        attacks = ((occ | line_starts) - 2*sliders) XOR (occ | line_starts)
+// for all sliders at once (the borrow of each slider ripples through the empty tiles up to its first blocker; the
+// first tile of the next line is made a virtual blocker so that a borrow never leaves its line).  So the board is kept
+// in two layouts — N (bit = row*W+col, the reference's) and T (bit = col*W+row) — and their bit-reversals are formed
+// on the fly (v_bfrev_b32): in each of the four layouts one ray direction is "+1":
+//        T : V+ (row+)      rev(T) : V- (row-)      N : H+ (col+)      rev(N) : H- (col-)
+// which also defines the ROLLOUT ORDER (ascending bit index inside each direction's own layout; oracle: rollout_key()).
+// Captures / shieldwall / king logic / enclosure / exit fort / repetition are the Engine's code on the N layout, so the
+// only new logic here is move generation, move picking and the upkeep of the T layout.
+//
+// The enclosure flood (logic.rs:720-734) is skipped when it provably cannot succeed: if any defender stands on an edge
+// tile or has a play that lands on one, then either that piece shares the king's region — which then touches an edge and
+// `find_enclosure(.., abort_on_edge = true, ..)` is None — or it is outside it and `occupied.len() == count(Defender)`
+// fails.  The opponent's plays are generated anyway (no-plays test + next ply), so the filter is free.
+//
+// Preconditions on the rules (checked by fast_ok(), else the generic Engine::rollout runs): no slow pieces, and an empty
+// throne may be crossed by every piece (throne_movement in {NoThrone, NoEntry, KingEntry}).
+#pragma once
+#include "tafl_core.hpp"
+
+namespace tafl {
+
+template <int NL> constexpr uint32_t bitrev32_ct(uint32_t v) {
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+TAFL_HD uint32_t bitrev32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+// whole-word reversal: bit i -> bit NL*32-1-i
+template <int NL> TAFL_HD Bits<NL> rev(const Bits<NL>& a) { Bits<NL> o; TAFL_UNROLL for (int i = 0; i < NL; ++i) o.w[i] = bitrev32(a.w[NL - 1 - i]); return o; }
+template <int NL> constexpr Bits<NL> rev_ct(const Bits<NL>& a) { Bits<NL> o{}; for (int i = 0; i < NL; ++i) o.w[i] = bitrev32_ct<NL>(a.w[NL - 1 - i]); return o; }
+// a - b over NL limbs
+template <int NL> TAFL_HD Bits<NL> sub(const Bits<NL>& a, const Bits<NL>& b) {
+    Bits<NL> o; uint32_t borrow = 0;
+    TAFL_UNROLL for (int i = 0; i < NL; ++i) {
+        const uint64_t d = (uint64_t)a.w[i] - (uint64_t)b.w[i] - (uint64_t)borrow;
+        o.w[i] = (uint32_t)d; borrow = (uint32_t)(d >> 63);
+    }
+    return o;
+}
+
+// constants of the fast engine, all derived from Consts (literals when Consts is constexpr)
+template <int NL>
+struct FastConsts {
+    Bits<NL> vb, vbr;        // virtual blockers: first tile of every line (N/T layouts) / reversed layouts
+    Bits<NL> em, emr;        // legal "+1" destinations: board minus the line starts
+    Bits<NL> lfs[2], lfsr[2];  // landing forbidden: attacker soldier, defender soldier
+    Bits<NL> lfk, lfkr;      // landing forbidden: king
+    Bits<NL> edge, edger;
+};
+template <int NL>
+constexpr FastConsts<NL> make_fast_consts(const Consts<NL>& C) {
+    FastConsts<NL> F{};
+    Bits<NL> emr_n{};
+    for (int i = 0; i < NL; ++i) {
+        F.vb.w[i] = C.col0.w[i]; F.em.w[i] = C.board.w[i] & ~C.col0.w[i];
+        emr_n.w[i] = C.board.w[i] & ~C.coln.w[i];
+        F.lfs[0].w[i] = C.land_forbid[CLS_ATT].w[i]; F.lfs[1].w[i] = C.land_forbid[CLS_DEF].w[i]; F.lfk.w[i] = C.land_forbid[CLS_KING].w[i];
+        F.edge.w[i] = C.edge.w[i];
+    }
+    F.vbr = rev_ct<NL>(C.coln); F.emr = rev_ct<NL>(emr_n);
+    F.lfsr[0] = rev_ct<NL>(F.lfs[0]); F.lfsr[1] = rev_ct<NL>(F.lfs[1]); F.lfkr = rev_ct<NL>(F.lfk); F.edger = rev_ct<NL>(F.edge);
+    return F;
+}
+template <int NL>
+constexpr bool fast_ok(const Consts<NL>& C) {
+    if (C.slow[0] || C.slow[1] || C.slow[2]) return false;
+    const uint8_t t = C.rules.throne_movement;
+    return t == TAFL_THRONE_NOTHRONE || t == TAFL_THRONE_NOENTRY || t == TAFL_THRONE_KINGENTRY;
+}
+
+template <int NL, int W>
+struct Fast {
+    using E = Engine<NL, W>;
+    using B = Bits<NL>;
+    using S = DState<NL>;
+    using K = Consts<NL>;
+    using F = FastConsts<NL>;
+    static constexpr uint32_t Z = NL * 32 - 1;
+
+    struct Gen {                 // destination sets, each in the layout of its own direction
+        B r[4];
+        uint32_t cnt[4], total;
+        bool edge_hit;           // some play of the side lands on an edge tile
+    };
+
+    static TAFL_HD uint32_t n_to_t(uint32_t idx) { return (idx % (uint32_t)W) * (uint32_t)W + idx / (uint32_t)W; }
+
+    // all rays in the +1 direction: attack set (first blocker included) of every slider at once
+    static TAFL_HD B fill(const B& occ, const B& sliders, const B& vblock) {
+        const B op = occ | vblock;
+        return sub(op, shl<1>(sliders)) ^ op;
+    }
+    // plays of `side` (0 attacker / 1 defender) in one layout: occ/mine/kbit in that layout
+    static TAFL_HD B reach1(const B& occ, const B& mine, const B& kbit, const B& vblock, const B& em, const B& lfs, const B& lfk, bool with_king) {
+        const B open = andn(em, occ);
+        if (!with_king) return andn(fill(occ, mine, vblock) & open, lfs);
+        // soldiers and king separately: they differ only in the tiles they may stop on (pieces of either kind block alike)
+        return andn(fill(occ, andn(mine, kbit), vblock) & open, lfs) | andn(fill(occ, kbit, vblock) & open, lfk);
+    }
+    static TAFL_HD void gen(const S& st, const B& attT, const B& defT, uint32_t side, const K& C, const F& fc, bool any_king_lane, Gen& g) {
+        const B occN = (st.att | st.def) & C.board, occT = (attT | defT) & C.board;
+        const B mineN = (side ? st.def : st.att) & C.board, mineT = (side ? defT : attT) & C.board;
+        const uint32_t k = E::king_sq(st, C);
+        B kN = bz<NL>(), kT = bz<NL>();
+        if (any_king_lane) {
+            const bool kalive = side && k != TAFL_NO_SQ;
+            const uint32_t ks = kalive ? k : 0u;
+            kN = gate(bit_at<NL>(ks) & st.def, kalive); kT = gate(bit_at<NL>(n_to_t(ks)) & defT, kalive);
+        }
+        const B lfs = blend(side != 0, fc.lfs[1], fc.lfs[0]), lfsr = blend(side != 0, fc.lfsr[1], fc.lfsr[0]);
+        g.r[0] = reach1(occT, mineT, kT, fc.vb, fc.em, lfs, fc.lfk, any_king_lane);
+        g.r[1] = reach1(rev(occT), rev(mineT), rev(kT), fc.vbr, fc.emr, lfsr, fc.lfkr, any_king_lane);
+        g.r[2] = reach1(occN, mineN, kN, fc.vb, fc.em, lfs, fc.lfk, any_king_lane);
+        g.r[3] = reach1(rev(occN), rev(mineN), rev(kN), fc.vbr, fc.emr, lfsr, fc.lfkr, any_king_lane);
+        g.total = 0;
+        TAFL_UNROLL for (int d = 0; d < 4; ++d) { g.cnt[d] = popc(g.r[d]); g.total += g.cnt[d]; }
+        g.edge_hit = any(((g.r[0] | g.r[2]) & fc.edge) | ((g.r[1] | g.r[3]) & fc.edger));
+    }
+
+    // idx-th play in ROLLOUT ORDER
+    static TAFL_HD Move pick(const S& st, const B& attT, const B& defT, const Gen& g, uint32_t idx, const K& C) {
+        uint32_t d = 0;
+        if (idx >= g.cnt[0]) { idx -= g.cnt[0]; d = 1;
+            if (idx >= g.cnt[1]) { idx -= g.cnt[1]; d = 2;
+                if (idx >= g.cnt[2]) { idx -= g.cnt[2]; d = 3; } } }
+        const bool odd = (d & 1u) != 0, horiz = d >= 2;
+        const B rsel = blend(horiz, blend(odd, g.r[3], g.r[2]), blend(odd, g.r[1], g.r[0]));
+        const B occb = blend(horiz, st.att | st.def, attT | defT) & C.board;
+        const B occ = blend(odd, rev(occb), occb);
+        const uint32_t x = nth_set_bit(rsel, idx);                       // destination, layout index
+        const uint32_t s = msb(occ & below<NL>(x));                      // nearest piece behind it = the mover
+        const uint32_t ux = odd ? Z - x : x, us = odd ? Z - s : s;       // un-reverse
+        const uint32_t qx = ux / (uint32_t)W, mx = ux % (uint32_t)W, qs = us / (uint32_t)W, ms = us % (uint32_t)W;
+        Move m;
+        m.to = horiz ? ux : mx * (uint32_t)W + qx;                       // T layout (col,row) -> N index
+        m.from = horiz ? us : ms * (uint32_t)W + qs;
+        m.dir = d; m.dist = odd ? us - ux : ux - us;
+        return m;
+    }
+
+    static TAFL_HD void transpose_in(const B& n, B& t) {
+        t = bz<NL>();
+        B r = n;
+        while (any(r)) { const uint32_t i = lsb(r); r = andn(r, bit_at<NL>(i)); t |= bit_at<NL>(n_to_t(i)); }
+    }
+
+    // one seeded uniform-random playout; identical results to Engine::rollout
+    static TAFL_HD void rollout(S& st, uint32_t sk, uint32_t max_plies, const K& C, tafl_rollout_result& res) {
+        const F fc = make_fast_consts<NL>(C);
+        const uint32_t start_side = st.flags & TAFL_F_SIDE;
+        B attT, defT;
+        transpose_in(st.att & C.board, attT); transpose_in(st.def & C.board, defT);
+        Gen g;
+        if (TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) gen(st, attT, defT, start_side, C, fc, true, g);
+        else { TAFL_UNROLL for (int d = 0; d < 4; ++d) { g.r[d] = bz<NL>(); g.cnt[d] = 0; } g.total = 0; g.edge_hit = false; }
+        uint32_t ply = 0; bool stuck = false;
+        while (ply < max_plies && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
+            if (g.total == 0) { stuck = true; break; }
+            const uint32_t idx = E::mulhi(E::ply_rand(sk, ply), g.total);
+            const Move m = pick(st, attT, defT, g, idx, C);
+            typename E::ApplyCtx ax;
+            E::apply_pre(st, m, C, ax);
+            // T layout upkeep: the move, then the (rare) captures
+            {
+                const B fT = bit_at<NL>(n_to_t(m.from)), tT = bit_at<NL>(n_to_t(m.to));
+                if (ax.mover) { defT = andn(defT, fT) | tT; attT = andn(attT, tT); } else { attT = andn(attT, fT) | tT; defT = andn(defT, tT); }
+                B c = ax.caps;
+                while (any(c)) { const uint32_t i = lsb(c); c = andn(c, bit_at<NL>(i)); const B cb = bit_at<NL>(n_to_t(i)); attT = andn(attT, cb); defT = andn(defT, cb); }
+            }
+            // opponent's plays on the post-move board: no-plays test, enclosure filter, and the next ply's move set
+            gen(st, attT, defT, ax.mover ^ 1u, C, fc, true, g);
+            const bool skip_encl = ax.mover == 0 && C.rules.enclosure_win == TAFL_ENCL_WITHOUT_EDGE_ACCESS
+                                   && (g.edge_hit || any(st.def & C.edge));
+            const typename E::Outcome o = E::outcome_early(st, ax, C, skip_encl);
+            E::apply_finish(st, ax, o, o.over ? 1u : g.total, C);
+            ++ply;
+        }
+        E::finish_rollout(st, start_side, ply, stuck, res);
+    }
+};
+
+}  // namespace tafl

@@ -8,6 +8,7 @@
 #pragma once
 #include <math.h>
 #include "tafl_core.hpp"
+#include "tafl_fast.hpp"
 
 namespace tafl {
 
@@ -181,12 +182,19 @@ struct Ops {
         if (eff) *eff = e;
         if (out_play) *out_play = pl;
     }
-    static TAFL_HD void rollout(S st, uint64_t seed, uint64_t game_id, uint32_t sim, uint32_t max_plies, const K& C, tafl_rollout_result& r) {
-        E::rollout(st, E::sim_key(E::game_key(seed, game_id), sim), max_plies, C, r);
+    // playout dispatcher: the fast two-layout engine whenever the rules allow it (tafl_fast.hpp), else the generic one.
+    // `force_generic` exists for the differential tests only.
+    static TAFL_HD void playout(S& st, uint32_t sk, uint32_t max_plies, const K& C, tafl_rollout_result& r, bool force_generic = false) {
+        if (fast_ok<NL>(C) && !force_generic) Fast<NL, W>::rollout(st, sk, max_plies, C, r);
+        else E::rollout(st, sk, max_plies, C, r);
     }
-    static TAFL_HD void random_advance(S& st, uint64_t seed, uint64_t game_id, uint32_t plies, const K& C) {
+    static TAFL_HD void rollout(S st, uint64_t seed, uint64_t game_id, uint32_t sim, uint32_t max_plies, const K& C, tafl_rollout_result& r,
+                                bool force_generic = false) {
+        playout(st, E::sim_key(E::game_key(seed, game_id), sim), max_plies, C, r, force_generic);
+    }
+    static TAFL_HD void random_advance(S& st, uint64_t seed, uint64_t game_id, uint32_t plies, const K& C, bool force_generic = false) {
         tafl_rollout_result r;
-        E::rollout(st, E::sim_key(E::game_key(seed, game_id), 0xFFFFFFFFu), plies, C, r);
+        playout(st, E::sim_key(E::game_key(seed, game_id), 0xFFFFFFFFu), plies, C, r, force_generic);
     }
 
     // ---- MCTS -------------------------------------------------------------------------------------------------
@@ -303,7 +311,7 @@ struct Ops {
         if (M.kind[g] != 1) return;
         S st; IO::load_rec(M.node_state + ((size_t)M.leaf[g] * M.G + g) * IO::QUADS, st);
         tafl_rollout_result r;
-        E::rollout(st, E::sim_key(E::game_key(seed, game_id), sim), max_plies, C, r);
+        playout(st, E::sim_key(E::game_key(seed, game_id), sim), max_plies, C, r);
         M.rvalue[g] = r.value;
         ls.rollouts += 1; ls.rollout_plies += r.plies; ls.reason = r.reason;
     }

@@ -11,6 +11,8 @@
 
 using namespace tafl;
 
+static bool g_force_generic = false;   // differential tests: generic Engine::rollout vs the fast playout engine
+
 template <int NL, int W>
 struct Host {
     using O = Ops<NL, W>;
@@ -51,12 +53,12 @@ struct Host {
     }
     static int rollout(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t cnt, uint64_t seed, uint32_t sim, uint32_t max_plies, uint64_t base, tafl_rollout_result* out) {
         K C; if (consts(r, n, C)) return -1;
-        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::rollout(s, seed, base + g, sim, max_plies, C, out[g]); }
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::rollout(s, seed, base + g, sim, max_plies, C, out[g], g_force_generic); }
         return 0;
     }
     static int random_advance(const tafl_rules* r, uint8_t n, tafl_state* st, uint32_t cnt, uint64_t seed, const uint32_t* plies, uint64_t base) {
         K C; if (consts(r, n, C)) return -1;
-        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::random_advance(s, seed, base + g, plies[g], C); state_to_abi<NL>(s, n, st[g]); }
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::random_advance(s, seed, base + g, plies[g], C, g_force_generic); state_to_abi<NL>(s, n, st[g]); }
         return 0;
     }
     static int mcts(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t G, const tafl_mcts_params* p, uint64_t base,
@@ -106,6 +108,7 @@ struct Host {
     }
 
 extern "C" {
+void hs_force_generic(int on) { g_force_generic = on != 0; }
 int hs_movegen(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint32_t* counts, uint32_t* masks, uint32_t mw) { DISPATCH(movegen(r, n, st, cnt, counts, masks, mw)) }
 int hs_validate(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_play* plays, uint8_t* codes) { DISPATCH(validate(r, n, st, cnt, plays, codes)) }
 int hs_step(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const tafl_play* plays, tafl_effects* eff) { DISPATCH(step(r, n, st, cnt, plays, eff)) }

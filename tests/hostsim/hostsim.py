@@ -32,6 +32,8 @@ def lib():
         sig("hs_rollout", P(TaflState), u32, u64, u32, u32, u64, P(TaflRolloutResult))
         sig("hs_random_advance", P(TaflState), u32, u64, P(u32), u64)
         sig("hs_mcts", P(TaflState), u32, P(TaflMctsParams), u64, P(TaflRootChild), u32, P(u32), P(TaflMctsStats))
+        L.hs_force_generic.restype = None
+        L.hs_force_generic.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 
@@ -87,3 +89,8 @@ class HostSim:
         stats = TaflMctsStats()
         assert lib().hs_mcts(*self._h(), states, n, C.byref(params), base, kids, max_children, cnt, C.byref(stats)) == 0
         return kids, cnt, stats
+
+
+def force_generic(on: bool):
+    """Differential tests: make host-sim playouts use the generic Engine::rollout instead of the fast engine."""
+    lib().hs_force_generic(int(on))
