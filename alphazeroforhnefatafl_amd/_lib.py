@@ -10,7 +10,7 @@ from .abi import (TaflEffects, TaflMctsParams, TaflMctsStats, TaflPlay, TaflRoll
                   TaflState)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtaflhip.so")
+LIB_PATH = os.environ.get("TAFLHIP_LIB") or os.path.join(_HERE, "libtaflhip.so")   # override: timing experiments only
 _LIB = None
 
 # every symbol include/taflhip.h declares: (name, restype, argtypes)

@@ -310,11 +310,9 @@ struct Engine {
     // ---- enclosure: bitboard flood (replaces the span fill of logic.rs:309-401) -----------------------------
     // inside: tiles that can be filled (empty + enclosed piece types); neither: pieces that abort the search.
     // Returns false for `None`.  fill = occupied ∪ unoccupied; boundary = enclosing pieces adjacent to the fill.
-    static TAFL_HD bool flood(uint32_t start_sq, const B& inside, const B& neither, bool abort_edge, bool abort_corner,
-                              const K& C, B& fill) {
-        if (start_sq == TAFL_NO_SQ) return false;
-        B f = bit_at<NL>(start_sq) & inside;
-        if (!any(f)) return false;
+    static TAFL_HD bool flood_from(const B& start, const B& inside, const B& neither, bool abort_edge, bool abort_corner,
+                                   const K& C, B& fill) {
+        B f = start;
         B stopmask = bz<NL>();
         if (abort_edge) stopmask |= C.edge;
         if (abort_corner) stopmask |= C.corners;
@@ -328,6 +326,13 @@ struct Engine {
         }
         fill = f;
         return true;
+    }
+    static TAFL_HD bool flood(uint32_t start_sq, const B& inside, const B& neither, bool abort_edge, bool abort_corner,
+                              const K& C, B& fill) {
+        if (start_sq == TAFL_NO_SQ) return false;
+        const B f = bit_at<NL>(start_sq) & inside;
+        if (!any(f)) return false;
+        return flood_from(f, inside, neither, abort_edge, abort_corner, C, fill);
     }
 
     // enclosure_secure (logic.rs:408-463) for a boundary made of soldiers of class `bcls`
@@ -361,10 +366,21 @@ struct Engine {
         if (!any(kt & C.edge)) return false;
         const B occ = st.att | st.def;
         const B empty = andn(C.board, occ);
+        const B attb = st.att & C.board;
+        // start tile: a defender there is the king (enclosed type), empty is enclosed, an attacker aborts (logic.rs:320-327)
+        if (any(kt & attb)) return false;
+        // first two rings of the flood unrolled: they decide almost every case (an attacker next to the growing region
+        // aborts, logic.rs:288-291), and the first ring is also the "king has space to move" test (logic.rs:590)
+        const B d1 = dilate(kt, C);
+        if (any(d1 & attb)) return false;
+        if (!any(d1 & empty)) return false;
+        const B f1 = kt | (d1 & empty);
+        if (any(f1 & C.corners)) return false;
+        const B d2 = dilate(f1, C);
+        if (any(d2 & attb)) return false;
         const B inside = empty | (kt & st.def);
         B fill;
-        if (!flood(k, inside, st.att & C.board, false, true, C, fill)) return false;
-        if (!any(dilate(kt, C) & empty)) return false;
+        if (!flood_from(f1 | (d2 & inside), inside, attb, false, true, C, fill)) return false;
         const B boundary = dilate(fill, C) & andn(st.def, fill);
         return secure(st, fill, boundary, CLS_DEF, true, false, C);
     }
@@ -449,8 +465,13 @@ struct Engine {
             }
             caps |= cs;
             // enemy king next to the destination (only an attacker can face it)
-            if (mover == 0 && any(dilate(tbit, C) & kb)) {
-                const uint32_t k = king_sq(st, C);
+#ifndef TAFL_ABLATE_KINGCAP
+            const uint32_t kq = king_sq(st, C);
+            const uint32_t kd = m.to > kq ? m.to - kq : kq - m.to;
+            const bool king_adjacent = mover == 0 && kq != TAFL_NO_SQ && any(kb)
+                                       && (kd == (uint32_t)W || (kd == 1u && m.to / (uint32_t)W == kq / (uint32_t)W));
+            if (king_adjacent) {
+                const uint32_t k = kq;
                 const B hk = (st.att & C.board) | (empty & C.hostile_special[CLS_KING]);   // tile_hostile(·, king)
                 const bool ehk = C.edge_hostile[CLS_KING] != 0;
                 const bool beside = any(kb & C.throne_nb);
@@ -485,8 +506,24 @@ struct Engine {
                 }
                 if (captured) caps |= kb;
             }
+#endif
         }
-        if (any(tbit & C.edge)) caps |= shieldwall(st, m.to, mover, C);
+#ifndef TAFL_ABLATE_SW
+        if (C.rules.has_shieldwall && any(tbit & C.edge)) {
+            // A wall captures only if >= 2 enemy pieces stand in a row next to `to` along its edge (logic.rs:507,527,556):
+            // test those two tiles before paying for the edge walk (with 64 games per wave the walk would otherwise run on
+            // every ply: 23 % of plays end on an edge, 0.3 % pass this test).
+            const B theirs = mover ? st.att : st.def;
+            const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W, n = C.n;
+            bool cand = false;
+            if (r == 0 || r == n - 1)
+                cand = (c + 2 < n && test(theirs, m.to + 1) && test(theirs, m.to + 2)) || (c >= 2 && test(theirs, m.to - 1) && test(theirs, m.to - 2));
+            if (c == 0 || c == n - 1)
+                cand = cand || (r + 2 < n && test(theirs, m.to + (uint32_t)W) && test(theirs, m.to + 2u * (uint32_t)W))
+                            || (r >= 2 && test(theirs, m.to - (uint32_t)W) && test(theirs, m.to - 2u * (uint32_t)W));
+            if (cand) caps |= shieldwall(st, m.to, mover, C);
+        }
+#endif
         return caps;
     }
 
@@ -532,7 +569,9 @@ struct Engine {
         ax.king_captured = mover == 0 && king_sq(st, C) != TAFL_NO_SQ && test(caps, king_sq(st, C));
         st.att = andn(st.att, caps); st.def = andn(st.def, caps);
         ax.ncap = popc(caps); ax.caps = caps; ax.mover = mover; ax.mover_is_king = mover_is_king; ax.tbit = tbit;
+#ifndef TAFL_ABLATE_TRACK
         track(st, mover, m, ax.ncap != 0);
+#endif
         if (ax.ncap == 0) st.psc += 1;
     }
     // skip_enclosure: the caller has PROVED that the enclosure win cannot apply (see tafl_fast.hpp); never set otherwise.
@@ -543,6 +582,7 @@ struct Engine {
         if (!any(other)) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_ALL_CAPTURED; o.winner = mover; o.over = true; }
         if (!o.over && mover == 0) {
             if (ax.king_captured) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_KING_CAPTURED; o.winner = 0; o.over = true; }
+#ifndef TAFL_ABLATE_FLOOD
             else if (C.rules.enclosure_win != TAFL_ENCL_NONE && !skip_enclosure) {
                 B fill;
                 const B inside = andn(C.board, st.att);
@@ -555,12 +595,16 @@ struct Engine {
                     }
                 }
             }
+#endif
         } else if (!o.over) {
             if (ax.mover_is_king && any(ax.tbit & (C.rules.edge_escape ? C.edge : C.corners))) {
                 o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_KING_ESCAPED; o.winner = 1; o.over = true;
-            } else if (C.rules.exit_fort && exit_fort(st, C)) {
+            }
+#ifndef TAFL_ABLATE_FORT
+            else if (C.rules.exit_fort && exit_fort(st, C)) {
                 o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_EXIT_FORT; o.winner = 1; o.over = true;
             }
+#endif
         }
         if (!o.over && C.rules.has_repetition_rule) {
             const uint32_t reps = mover ? (st.reps >> 16) : (st.reps & 0xFFFFu);
