@@ -71,18 +71,15 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from alphazeroforhnefatafl_amd import dist as tdist
+    rank, local_rank, world = tdist.env_rank_world()
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    tdist.init("nccl", rank, world)          # RCCL: only for the barrier and the max-reduce of the elapsed time
 
     from alphazeroforhnefatafl_amd import abi
     from alphazeroforhnefatafl_amd.engine import KC_MCTS_BACKUP, KC_MCTS_ROLLOUT, KC_MCTS_TREE, BatchedGameLogic
@@ -92,15 +89,14 @@ def main():
     G = args.games
     batch = logic.new_batch(G, abi.boards.COPENHAGEN)        # synthetic data: every game at the start position
     batch.mcts_reserve(args.sims)
-    base = rank * G                                           # contiguous global game-id shards, no collective on the data path
+    base = tdist.shard_base(rank, G)                          # contiguous global game-id shards, no collective on the data path
 
     def step():
         batch.mcts_run(args.sims, args.cpuct, args.seed, args.max_plies, game_id_base=base)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        tdist.barrier(world)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -119,14 +115,11 @@ def main():
     tree_ms, tree_n = logic.timing_get(KC_MCTS_TREE)
     bk_ms, bk_n = logic.timing_get(KC_MCTS_BACKUP)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = tdist.max_over_ranks(elapsed, world, device="cuda")
 
     total_sims = float(world) * G * args.sims * args.steps
     plies_per_step = float(stats.rollout_plies)
-    total_plies = plies_per_step * args.steps * world          # identical workload per rank up to RNG ids
+    total_plies = tdist.sum_over_ranks(plies_per_step, world, device="cuda") * args.steps
     if rank == 0:
         avg_roll_s = (roll_ms / max(roll_n, 1)) * 1e-3
         achieved = (ROLLOUT_BYTES_PER_GAME * G) / avg_roll_s / 1e9 if avg_roll_s > 0 else 0.0
