@@ -509,18 +509,19 @@ struct Engine {
 #endif
         }
 #ifndef TAFL_ABLATE_SW
-        if (C.rules.has_shieldwall && any(tbit & C.edge)) {
+        if (C.rules.has_shieldwall) {
             // A wall captures only if >= 2 enemy pieces stand in a row next to `to` along its edge (logic.rs:507,527,556):
             // test those two tiles before paying for the edge walk (with 64 games per wave the walk would otherwise run on
             // every ply: 23 % of plays end on an edge, 0.3 % pass this test).
-            const B theirs = mover ? st.att : st.def;
+            const B theirs = blend(mover != 0, st.att, st.def);
             const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W, n = C.n;
-            bool cand = false;
-            if (r == 0 || r == n - 1)
-                cand = (c + 2 < n && test(theirs, m.to + 1) && test(theirs, m.to + 2)) || (c >= 2 && test(theirs, m.to - 1) && test(theirs, m.to - 2));
-            if (c == 0 || c == n - 1)
-                cand = cand || (r + 2 < n && test(theirs, m.to + (uint32_t)W) && test(theirs, m.to + 2u * (uint32_t)W))
-                            || (r >= 2 && test(theirs, m.to - (uint32_t)W) && test(theirs, m.to - 2u * (uint32_t)W));
+            // straight-line on purpose (no short-circuit): with one wave per SIMD every branch costs tens of cycles
+            const uint32_t hp = (uint32_t)test(theirs, m.to + 1) & (uint32_t)test(theirs, m.to + 2) & (uint32_t)(c + 2 < n);
+            const uint32_t hm = (uint32_t)test(theirs, m.to - 1) & (uint32_t)test(theirs, m.to - 2) & (uint32_t)(c >= 2);
+            const uint32_t vp = (uint32_t)test(theirs, m.to + (uint32_t)W) & (uint32_t)test(theirs, m.to + 2u * (uint32_t)W) & (uint32_t)(r + 2 < n);
+            const uint32_t vm = (uint32_t)test(theirs, m.to - (uint32_t)W) & (uint32_t)test(theirs, m.to - 2u * (uint32_t)W) & (uint32_t)(r >= 2);
+            const uint32_t row_edge = (uint32_t)(r == 0) | (uint32_t)(r == n - 1), col_edge = (uint32_t)(c == 0) | (uint32_t)(c == n - 1);
+            const bool cand = ((row_edge & (hp | hm)) | (col_edge & (vp | vm))) != 0;
             if (cand) caps |= shieldwall(st, m.to, mover, C);
         }
 #endif
@@ -558,13 +559,15 @@ struct Engine {
         const B fbit = bit_at<NL>(m.from), tbit = bit_at<NL>(m.to);
         const bool mover_is_king = mover && m.from == king_sq(st, C);
         // board.move_piece (board/state.rs:218-223)
-        if (mover) {
-            st.def = andn(st.def, fbit) | tbit; st.att = andn(st.att, tbit);
-            if (mover_is_king) {
-                const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W;
-                st.flags = (st.flags & ~0x00FF0000u) | (r << 16) | (c << 20);
-            }
-        } else { st.att = andn(st.att, fbit) | tbit; st.def = andn(st.def, tbit); }
+        {
+            // mover side: clear `from`, set `to`; other side: clear `to` (set_piece, board/state.rs:149-165) — branch-free
+            const B dm = gate(fbit | tbit, mover != 0), am = gate(fbit | tbit, mover == 0);
+            st.def = andn(st.def, dm | tbit) | gate(tbit, mover != 0);
+            st.att = andn(st.att, am | tbit) | gate(tbit, mover == 0);
+            const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W;
+            const uint32_t kf = (st.flags & ~0x00FF0000u) | (r << 16) | (c << 20);
+            st.flags = mover_is_king ? kf : st.flags;
+        }
         const B caps = captures(st, m, mover, mover_is_king, C);
         ax.king_captured = mover == 0 && king_sq(st, C) != TAFL_NO_SQ && test(caps, king_sq(st, C));
         st.att = andn(st.att, caps); st.def = andn(st.def, caps);

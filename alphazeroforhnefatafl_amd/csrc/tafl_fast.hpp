@@ -133,10 +133,10 @@ struct Fast {
 
     // idx-th play in ROLLOUT ORDER
     static TAFL_HD Move pick(const S& st, const B& attT, const B& defT, const Gen& g, uint32_t idx, const K& C) {
-        uint32_t d = 0;
-        if (idx >= g.cnt[0]) { idx -= g.cnt[0]; d = 1;
-            if (idx >= g.cnt[1]) { idx -= g.cnt[1]; d = 2;
-                if (idx >= g.cnt[2]) { idx -= g.cnt[2]; d = 3; } } }
+        // direction by prefix sums, branch-free
+        const uint32_t c0 = g.cnt[0], c1 = c0 + g.cnt[1], c2 = c1 + g.cnt[2];
+        const uint32_t d = (uint32_t)(idx >= c0) + (uint32_t)(idx >= c1) + (uint32_t)(idx >= c2);
+        idx -= d == 0 ? 0u : d == 1 ? c0 : d == 2 ? c1 : c2;
         const bool odd = (d & 1u) != 0, horiz = d >= 2;
         const B rsel = blend(horiz, blend(odd, g.r[3], g.r[2]), blend(odd, g.r[1], g.r[0]));
         const B occb = blend(horiz, st.att | st.def, attT | defT) & C.board;
@@ -177,7 +177,8 @@ struct Fast {
             // T layout upkeep: the move, then the (rare) captures
             {
                 const B fT = bit_at<NL>(n_to_t(m.from)), tT = bit_at<NL>(n_to_t(m.to));
-                if (ax.mover) { defT = andn(defT, fT) | tT; attT = andn(attT, tT); } else { attT = andn(attT, fT) | tT; defT = andn(defT, tT); }
+                defT = andn(defT, gate(fT, ax.mover != 0) | tT) | gate(tT, ax.mover != 0);
+                attT = andn(attT, gate(fT, ax.mover == 0) | tT) | gate(tT, ax.mover == 0);
                 B c = ax.caps;
                 while (any(c)) { const uint32_t i = lsb(c); c = andn(c, bit_at<NL>(i)); const B cb = bit_at<NL>(n_to_t(i)); attT = andn(attT, cb); defT = andn(defT, cb); }
             }
