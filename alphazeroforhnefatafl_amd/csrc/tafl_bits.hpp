@@ -119,6 +119,19 @@ template <int NL> TAFL_HD Bits<NL> below(uint32_t idx) {
     TAFL_UNROLL for (int i = 0; i < NL; ++i) o.w[i] = ((uint32_t)i < wi) ? 0xFFFFFFFFu : (((uint32_t)i == wi) ? b : 0u);
     return o;
 }
+// 5-bit window around idx: bit k of the result = bit (idx - 2 + k) of a (bits outside the word read as 0)
+template <int NL> TAFL_HD uint32_t window5(const Bits<NL>& a, uint32_t idx) {
+    const Bits<NL> b = shl<2>(a);                      // bit (idx-2) of a is bit idx of b: no negative positions
+    const uint32_t wi = idx >> 5, off = idx & 31;
+    uint32_t lo = 0, hi = 0;
+    TAFL_UNROLL for (int i = 0; i < NL; ++i) {
+        const uint32_t ml = ((uint32_t)i == wi) ? 0xFFFFFFFFu : 0u, mh = ((uint32_t)i == wi + 1) ? 0xFFFFFFFFu : 0u;
+        lo |= b.w[i] & ml; hi |= b.w[i] & mh;
+    }
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)(v >> off) & 31u;
+}
+
 // position of the j-th (0-based) set bit of a 32-bit word, j < popcount(v)
 TAFL_HD uint32_t nth_set_bit32(uint32_t v, uint32_t j) {
     uint32_t pos = 0;

@@ -435,7 +435,8 @@ struct Engine {
         const B far_h = step1<OPP>(hostile, C) | gate(lastline<DIR>(C), edge_h);
         return nb & victims & far_h;
     }
-    static TAFL_HD B captures(const S& st, const Move& m, uint32_t mover, bool mover_is_king, const K& C) {
+    // sw_hint: -1 = evaluate the shieldwall pre-filter here; 0 / 1 = the caller already did (fast playout engine)
+    static TAFL_HD B captures(const S& st, const Move& m, uint32_t mover, bool mover_is_king, const K& C, int sw_hint = -1) {
         B caps = bz<NL>();
         const B tbit = bit_at<NL>(m.to);
         const B occ = st.att | st.def;
@@ -513,15 +514,19 @@ struct Engine {
             // A wall captures only if >= 2 enemy pieces stand in a row next to `to` along its edge (logic.rs:507,527,556):
             // test those two tiles before paying for the edge walk (with 64 games per wave the walk would otherwise run on
             // every ply: 23 % of plays end on an edge, 0.3 % pass this test).
-            const B theirs = blend(mover != 0, st.att, st.def);
-            const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W, n = C.n;
-            // straight-line on purpose (no short-circuit): with one wave per SIMD every branch costs tens of cycles
-            const uint32_t hp = (uint32_t)test(theirs, m.to + 1) & (uint32_t)test(theirs, m.to + 2) & (uint32_t)(c + 2 < n);
-            const uint32_t hm = (uint32_t)test(theirs, m.to - 1) & (uint32_t)test(theirs, m.to - 2) & (uint32_t)(c >= 2);
-            const uint32_t vp = (uint32_t)test(theirs, m.to + (uint32_t)W) & (uint32_t)test(theirs, m.to + 2u * (uint32_t)W) & (uint32_t)(r + 2 < n);
-            const uint32_t vm = (uint32_t)test(theirs, m.to - (uint32_t)W) & (uint32_t)test(theirs, m.to - 2u * (uint32_t)W) & (uint32_t)(r >= 2);
-            const uint32_t row_edge = (uint32_t)(r == 0) | (uint32_t)(r == n - 1), col_edge = (uint32_t)(c == 0) | (uint32_t)(c == n - 1);
-            const bool cand = ((row_edge & (hp | hm)) | (col_edge & (vp | vm))) != 0;
+            bool cand;
+            if (sw_hint >= 0) cand = sw_hint != 0;
+            else {
+                const B theirs = blend(mover != 0, st.att, st.def);
+                const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W, n = C.n;
+                // straight-line on purpose (no short-circuit): with one wave per SIMD every branch costs tens of cycles
+                const uint32_t hp = (uint32_t)test(theirs, m.to + 1) & (uint32_t)test(theirs, m.to + 2) & (uint32_t)(c + 2 < n);
+                const uint32_t hm = (uint32_t)test(theirs, m.to - 1) & (uint32_t)test(theirs, m.to - 2) & (uint32_t)(c >= 2);
+                const uint32_t vp = (uint32_t)test(theirs, m.to + (uint32_t)W) & (uint32_t)test(theirs, m.to + 2u * (uint32_t)W) & (uint32_t)(r + 2 < n);
+                const uint32_t vm = (uint32_t)test(theirs, m.to - (uint32_t)W) & (uint32_t)test(theirs, m.to - 2u * (uint32_t)W) & (uint32_t)(r >= 2);
+                const uint32_t row_edge = (uint32_t)(r == 0) | (uint32_t)(r == n - 1), col_edge = (uint32_t)(c == 0) | (uint32_t)(c == n - 1);
+                cand = ((row_edge & (hp | hm)) | (col_edge & (vp | vm))) != 0;
+            }
             if (cand) caps |= shieldwall(st, m.to, mover, C);
         }
 #endif
@@ -554,7 +559,7 @@ struct Engine {
     struct ApplyCtx { uint32_t mover; bool mover_is_king, king_captured; B tbit, caps; uint32_t ncap; };
     struct Outcome { bool over; uint32_t status, reason, winner; };
 
-    static TAFL_HD void apply_pre(S& st, const Move& m, const K& C, ApplyCtx& ax) {
+    static TAFL_HD void apply_pre(S& st, const Move& m, const K& C, ApplyCtx& ax, int sw_hint = -1) {
         const uint32_t mover = st.flags & TAFL_F_SIDE;
         const B fbit = bit_at<NL>(m.from), tbit = bit_at<NL>(m.to);
         const bool mover_is_king = mover && m.from == king_sq(st, C);
@@ -568,7 +573,7 @@ struct Engine {
             const uint32_t kf = (st.flags & ~0x00FF0000u) | (r << 16) | (c << 20);
             st.flags = mover_is_king ? kf : st.flags;
         }
-        const B caps = captures(st, m, mover, mover_is_king, C);
+        const B caps = captures(st, m, mover, mover_is_king, C, sw_hint);
         ax.king_captured = mover == 0 && king_sq(st, C) != TAFL_NO_SQ && test(caps, king_sq(st, C));
         st.att = andn(st.att, caps); st.def = andn(st.def, caps);
         ax.ncap = popc(caps); ax.caps = caps; ax.mover = mover; ax.mover_is_king = mover_is_king; ax.tbit = tbit;

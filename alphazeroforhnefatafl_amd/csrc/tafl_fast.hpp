@@ -172,8 +172,20 @@ struct Fast {
             if (g.total == 0) { stuck = true; break; }
             const uint32_t idx = E::mulhi(E::ply_rand(sk, ply), g.total);
             const Move m = pick(st, attT, defT, g, idx, C);
+            // shieldwall pre-filter (two enemy pieces in a row next to `to` along its edge, logic.rs:507,527,556) from 5-bit
+            // windows: row edges are lines of the N layout, column edges are lines of the T layout
+            int sw_hint = 0;
+            if (C.rules.has_shieldwall) {
+                const bool mv = (st.flags & TAFL_F_SIDE) != 0;
+                const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W, n = C.n;
+                const uint32_t wn = window5(blend(mv, st.att, st.def), m.to), wt = window5(blend(mv, attT, defT), n_to_t(m.to));
+                const uint32_t row_edge = (uint32_t)(r == 0) | (uint32_t)(r == n - 1), col_edge = (uint32_t)(c == 0) | (uint32_t)(c == n - 1);
+                const uint32_t h = ((uint32_t)((wn & 0x18u) == 0x18u) & (uint32_t)(c + 2 < n)) | ((uint32_t)((wn & 3u) == 3u) & (uint32_t)(c >= 2));
+                const uint32_t v = ((uint32_t)((wt & 0x18u) == 0x18u) & (uint32_t)(r + 2 < n)) | ((uint32_t)((wt & 3u) == 3u) & (uint32_t)(r >= 2));
+                sw_hint = (int)((row_edge & h) | (col_edge & v));
+            }
             typename E::ApplyCtx ax;
-            E::apply_pre(st, m, C, ax);
+            E::apply_pre(st, m, C, ax, sw_hint);
             // T layout upkeep: the move, then the (rare) captures
             {
                 const B fT = bit_at<NL>(n_to_t(m.from)), tT = bit_at<NL>(n_to_t(m.to));

@@ -81,3 +81,23 @@ def test_fast_rollouts_random_rulesets(seed):
     if n >= 9:
         lst += pu.exit_fort_positions(rng, n, wb, 40)
     _compare(rules, n, wb, pu.states_array(lst), len(lst), seed, 60, ("fuzz", seed))
+
+
+@pytest.mark.parametrize("n,wb", [(11, 128), (9, 128), (13, 256), (7, 64)])
+def test_fast_shieldwall_hint_many_seeds(n, wb):
+    """Very short playouts from wall-ready positions under many seeds: the wall-completing play is drawn often, so a
+    false negative of the fast engine's window pre-filter would show up as a different capture count / outcome."""
+    rng = random.Random(77)
+    rules = abi.rules.COPENHAGEN
+    variants = (rules, rules.replace(shieldwall=(False, abi.ps_all())))
+    lst = pu.shieldwall_positions(rng, n, wb, 150)
+    states = pu.states_array(lst)
+    lg0 = orc.GameLogic(rules, n)
+    # make sure the workload really contains wall captures: count multi-captures among all legal plays (oracle)
+    oc, _ = orc.batch_movegen(lg0, states, len(lst), wb)
+    arr, ranks, total, _ = pu.expand_all(states, len(lst), oc)
+    _, oe = orc.batch_step_kth(lg0, pu.clone_states(arr, total), total, wb, ranks)
+    assert sum(1 for i in range(total) if oe[i].n_captures >= 2) >= 20
+    for v in variants:
+        for seed in range(12):
+            _compare(v, n, wb, states, len(lst), 100 + seed, 3, ("swhint", n, seed))
