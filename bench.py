@@ -126,6 +126,11 @@ def main():
         d_bar = stats.tree_depth_sum / max(stats.sims, 1)
         c_bar = stats.children_scanned / max(stats.tree_depth_sum, 1)
         bytes_per_sim = d_bar * (64 + 16 * c_bar) + 32 + 2 * STATE_BYTES + 4     # SURVEY.md §8d formula
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_k_mcts_rollout.json")
+        if os.path.exists(tpath) and G == GAMES_PER_GPU:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")      # rocprofv3 PMC pass of this same command (profiles/)
         out = {
             "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -146,7 +151,8 @@ def main():
                            "k_mcts_tree": {"avg": tree_ms / max(tree_n, 1), "launches": int(tree_n)},
                            "k_mcts_tree(final backup)": {"avg": bk_ms / max(bk_n, 1), "launches": int(bk_n)}},
             "roofline": {"kernel": "k_mcts_rollout", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ROLLOUT_BYTES_PER_GAME * G,
                          "note": "register-resident playout: 68 algorithmic bytes per game per launch; the binding limit is "
                                  "integer VALU issue/latency, see DESIGN.md"},
         }
