@@ -84,16 +84,25 @@ TAFL_HD Bits<NL> shr(const Bits<NL>& a) {
     return o;
 }
 
-// run-time single-bit helpers (no dynamic register indexing: unrolled compare/select)
+// run-time single-bit helpers.  No dynamic register indexing (that becomes scratch); built on 64-bit halves so that one
+// v_lshl_b64 + a few selects replace a compare/select per 32-bit limb.
 template <int NL> TAFL_HD Bits<NL> bit_at(uint32_t idx) {
-    Bits<NL> o; const uint32_t wi = idx >> 5, b = 1u << (idx & 31);
-    TAFL_UNROLL for (int i = 0; i < NL; ++i) o.w[i] = ((uint32_t)i == wi) ? b : 0u;
+    Bits<NL> o;
+    const uint64_t b = 1ull << (idx & 63u);
+    const uint32_t h = idx >> 6;
+    TAFL_UNROLL for (int i = 0; i < NL / 2; ++i) {
+        const uint64_t v = (h == (uint32_t)i) ? b : 0ull;
+        o.w[2 * i] = (uint32_t)v; o.w[2 * i + 1] = (uint32_t)(v >> 32);
+    }
     return o;
 }
 template <int NL> TAFL_HD bool test(const Bits<NL>& a, uint32_t idx) {
-    const uint32_t wi = idx >> 5; uint32_t v = 0;
-    TAFL_UNROLL for (int i = 0; i < NL; ++i) v |= ((uint32_t)i == wi) ? a.w[i] : 0u;
-    return (v >> (idx & 31)) & 1u;
+    const uint32_t h = idx >> 6; uint64_t v = 0;
+    TAFL_UNROLL for (int i = 0; i < NL / 2; ++i) {
+        const uint64_t x = (uint64_t)a.w[2 * i] | ((uint64_t)a.w[2 * i + 1] << 32);
+        v |= (h == (uint32_t)i) ? x : 0ull;
+    }
+    return (v >> (idx & 63u)) & 1ull;
 }
 // index of lowest set bit (a must be non-zero)
 template <int NL> TAFL_HD uint32_t lsb(const Bits<NL>& a) {
@@ -113,10 +122,15 @@ template <int NL> TAFL_HD uint32_t msb(const Bits<NL>& a) {
     }
     return r;
 }
-// all bits strictly below idx
+// all bits strictly below idx (idx <= NL*32)
 template <int NL> TAFL_HD Bits<NL> below(uint32_t idx) {
-    Bits<NL> o; const uint32_t wi = idx >> 5, b = (1u << (idx & 31)) - 1u;
-    TAFL_UNROLL for (int i = 0; i < NL; ++i) o.w[i] = ((uint32_t)i < wi) ? 0xFFFFFFFFu : (((uint32_t)i == wi) ? b : 0u);
+    Bits<NL> o;
+    const uint64_t m = (1ull << (idx & 63u)) - 1ull;
+    const uint32_t h = idx >> 6;
+    TAFL_UNROLL for (int i = 0; i < NL / 2; ++i) {
+        const uint64_t v = ((uint32_t)i < h) ? ~0ull : (((uint32_t)i == h) ? m : 0ull);
+        o.w[2 * i] = (uint32_t)v; o.w[2 * i + 1] = (uint32_t)(v >> 32);
+    }
     return o;
 }
 // 5-bit window around idx: bit k of the result = bit (idx - 2 + k) of a (bits outside the word read as 0)

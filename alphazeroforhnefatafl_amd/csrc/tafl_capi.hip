@@ -24,6 +24,9 @@ using namespace tafl;
 // kernels
 // --------------------------------------------------------------------------------------------------
 #define TAFL_BLOCK 64
+#ifndef TAFL_KATTR
+#define TAFL_KATTR
+#endif
 
 template <int NL, int W>
 __global__ __launch_bounds__(TAFL_BLOCK) void k_fill(Quad* soa, uint32_t n, DState<NL> st) {
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_side_can_play(Consts<NL> C, cons
     const Consts<NL>& C = (PRESET != PRESET_NONE) ? C##_ct : (Carg)
 
 template <int NL, int W, int PRESET>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_rollout(Consts<NL> Carg, const Quad* soa, uint32_t n, uint64_t seed, uint32_t sim, uint32_t max_plies,
+__global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK) void k_rollout(Consts<NL> Carg, const Quad* soa, uint32_t n, uint64_t seed, uint32_t sim, uint32_t max_plies,
                                                         uint64_t base, tafl_rollout_result* out) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= n) return;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
 
 // the dominant kernel: one seeded random playout per game, state resident in registers
 template <int NL, int W, int PRESET>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim, uint32_t max_plies,
+__global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim, uint32_t max_plies,
                                                              unsigned long long* stats) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     TAFL_PICK_CONSTS(C, Carg);
