@@ -130,12 +130,13 @@ class TaflMctsParams(C.Structure):
 class TaflMctsStats(C.Structure):
     _fields_ = [("sims", C.c_uint64), ("rollouts", C.c_uint64), ("rollout_plies", C.c_uint64),
                 ("tree_depth_sum", C.c_uint64), ("children_scanned", C.c_uint64), ("terminal_hits", C.c_uint64),
-                ("reason_hist", C.c_uint64 * 16), ("faults", C.c_uint64)]
+                ("reason_hist", C.c_uint64 * 16), ("faults", C.c_uint64), ("spec_issued", C.c_uint64),
+                ("spec_hits", C.c_uint64)]
 
 
 EXPECTED_SIZES = {"tafl_rules": 32, "tafl_play": 4, "tafl_state": 104, "tafl_effects": 40,
                   "tafl_rollout_result": 8, "tafl_root_child": 24, "tafl_mcts_params": 32,
-                  "tafl_mcts_stats": 184}
+                  "tafl_mcts_stats": 200}
 for _name, _cls in [("tafl_rules", TaflRules), ("tafl_play", TaflPlay), ("tafl_state", TaflState),
                     ("tafl_effects", TaflEffects), ("tafl_rollout_result", TaflRolloutResult),
                     ("tafl_root_child", TaflRootChild), ("tafl_mcts_params", TaflMctsParams),

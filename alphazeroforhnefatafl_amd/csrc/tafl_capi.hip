@@ -113,7 +113,7 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_random_advance(Consts<NL> Carg, 
 }
 
 // ---- MCTS kernels ---------------------------------------------------------------------------------
-enum { ST_SIMS = 0, ST_ROLLOUTS, ST_PLIES, ST_DEPTH, ST_SCANNED, ST_TERMINAL, ST_FAULTS, ST_REASON0 = 8, ST_COUNT = 24 };
+enum { ST_SIMS = 0, ST_ROLLOUTS, ST_PLIES, ST_DEPTH, ST_SCANNED, ST_TERMINAL, ST_FAULTS, ST_SPEC_ISSUED, ST_REASON0 = 8, ST_SPEC_HITS = 24, ST_EXEC = 25, ST_COUNT = 28 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -132,34 +132,37 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_init(Consts<NL> C, const Qu
     Ops<NL, W>::mcts_init_game(M, g, st, C);
 }
 
-// backup of simulation i-1 fused with select/expand of simulation i (both walk the same tree arena)
+// tree phase of the simulation pipeline: consume finished playouts (backup), run as many further simulations as can be
+// served by ready slots, then issue the next slots (tafl_ops.hpp mcts_tree_step)
 template <int NL, int W, int PRESET>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, int do_backup, int do_select, unsigned long long* stats) {
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, unsigned long long* stats) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     TAFL_PICK_CONSTS(C, Carg);
     LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
-    if (g < M.G) {
-        if (do_backup) Ops<NL, W>::mcts_backup(M, g);
-        if (do_select) Ops<NL, W>::mcts_select_expand(M, g, c_puct, C, ls);
-    }
+    ls.reason_hist4 = 0; ls.spec_issued = ls.spec_hits = 0;
+    const bool live = g < M.G && (M.sim_next[g] < n_sims || M.kind[g] == 1);
+    if (__ballot(live) == 0ull) return;                       // whole wave finished: nothing to do, nothing to count
+    if (live) Ops<NL, W>::mcts_tree_step(M, g, c_puct, n_sims, C, ls);
     stat_add(stats, ST_SIMS, ls.sims); stat_add(stats, ST_DEPTH, ls.depth); stat_add(stats, ST_SCANNED, ls.scanned);
     stat_add(stats, ST_TERMINAL, ls.terminal_hits); stat_add(stats, ST_FAULTS, ls.faults);
+    stat_add(stats, ST_ROLLOUTS, ls.rollouts); stat_add(stats, ST_PLIES, ls.rollout_plies);
+    stat_add(stats, ST_SPEC_ISSUED, ls.spec_issued); stat_add(stats, ST_SPEC_HITS, ls.spec_hits);
+    for (uint32_t r = 0; r < 16; ++r) stat_add(stats, ST_REASON0 + r, (uint32_t)((ls.reason_hist4 >> (4u * r)) & 15ull));
 }
 
-// the dominant kernel: one seeded random playout per game, state resident in registers
+// the dominant kernel: one seeded random playout per (slot, game), state resident in registers.  Slot-major grid: block b
+// serves slot b / blocks_per_slot, so spec_k slots per game put up to spec_k waves on every SIMD.
 template <int NL, int W, int PRESET>
-__global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim, uint32_t max_plies,
-                                                             unsigned long long* stats) {
-    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+__global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim_offset,
+                                                                       uint32_t max_plies, uint32_t blocks_per_slot, unsigned long long* stats) {
+    const uint32_t j = blockIdx.x / blocks_per_slot;
+    const uint32_t g = (blockIdx.x % blocks_per_slot) * TAFL_BLOCK + threadIdx.x;
     TAFL_PICK_CONSTS(C, Carg);
-    LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
-    if (g < M.G) Ops<NL, W>::mcts_rollout(M, g, seed, base + g, sim, max_plies, C, ls);
-    stat_add(stats, ST_ROLLOUTS, ls.rollouts); stat_add(stats, ST_PLIES, ls.rollout_plies);
-    // termination-reason histogram: 16 ballots per wave
-    for (uint32_t r = 0; r < 16; ++r) {
-        const unsigned long long b = __ballot(ls.rollouts && ls.reason == r);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&stats[ST_REASON0 + r], (unsigned long long)__popcll(b));
-    }
+    const bool work = g < M.G && j < M.spec_n[g] && M.spec_kind[(size_t)j * M.G + g] == 1;
+    const unsigned long long wb = __ballot(work);
+    if (wb == 0ull) return;
+    if (work) Ops<NL, W>::mcts_slot_rollout(M, j, g, seed, base + g, sim_offset, max_plies, C);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&stats[ST_EXEC], (unsigned long long)__popcll(wb));
 }
 
 template <int NL, int W>
@@ -227,6 +230,8 @@ struct tafl_batch {
     // MCTS
     MctsMem mem; bool has_mem; uint32_t reserved_sims;
     DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, rvalue, fault, stats, children, children_n, visits;
+    DevBuf sim_next, spec_state, spec_value, spec_kind, spec_reason, spec_plies, spec_parent, spec_o0, spec_first, spec_n;
+    uint32_t spec_k;
     tafl_mcts_stats last_stats; bool ran;
 };
 
@@ -364,6 +369,7 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     tafl_batch* b = new (std::nothrow) tafl_batch();
     if (!b) return fail(TAFL_ERR_OOM, "out of host memory");
     b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr;
+    { const char* e = getenv("TAFL_SPEC_K"); int k = e ? atoi(e) : 4; b->spec_k = (uint32_t)(k < 1 ? 1 : (k > 8 ? 8 : k)); }
     memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats);
     const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
     if (hipMalloc((void**)&b->soa, bytes) != hipSuccess) { delete b; return fail(TAFL_ERR_OOM, "hipMalloc(batch states) failed"); }
@@ -379,7 +385,8 @@ int tafl_batch_destroy(tafl_batch* b) {
     if (b->soa) (void)hipFree(b->soa);
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
-                      &b->children, &b->children_n, &b->visits};
+                      &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_value, &b->spec_kind, &b->spec_reason,
+                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return TAFL_OK;
@@ -573,9 +580,17 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->node_top, n * 4); NEED(b->edge_top, n * 4); NEED(b->leaf, n * 4);
     NEED(b->kind, n); NEED(b->rvalue, n); NEED(b->fault, n);
     NEED(b->stats, sizeof(unsigned long long) * ST_COUNT);
+    const size_t k = b->spec_k;
+    NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * quads_of(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n);
+    NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_parent, n * 4); NEED(b->spec_o0, n * 4); NEED(b->spec_first, n * 4);
+    NEED(b->spec_n, n);
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
     b->mem.kind = (uint8_t*)b->kind.p; b->mem.rvalue = (int8_t*)b->rvalue.p; b->mem.fault = (uint8_t*)b->fault.p;
+    b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p;
+    b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
+    b->mem.spec_parent = (uint32_t*)b->spec_parent.p; b->mem.spec_o0 = (int32_t*)b->spec_o0.p; b->mem.spec_first = (uint32_t*)b->spec_first.p;
+    b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_k = b->spec_k;
     b->mem.G = b->n; b->mem.node_cap = (uint32_t)node_cap; b->mem.edge_cap = (uint32_t)edge_cap;
     b->has_mem = true; b->reserved_sims = max_sims;
     return TAFL_OK;
@@ -594,20 +609,23 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     unsigned long long* st = (unsigned long long*)b->stats.p;
     HIPCHK(hipMemsetAsync(st, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
     DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_init<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, M));
+    // Every tree launch completes at least one simulation per unfinished game, so n_sims rounds always suffice; with
+    // spec_k playout slots per game a round usually completes ~spec_k, and launches whose waves are all done return at once.
+    const uint32_t bps = grid_of(n);
     for (uint32_t i = 0; i < p->n_sims; ++i) {
         {
             SpanGuard sg(c, KC_MCTS_TREE);
-            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, i > 0 ? 1 : 0, 1, st));
+            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, st));
         }
         {
             SpanGuard sg(c, KC_MCTS_ROLLOUT);
-            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->seed, game_id_base,
-                                               p->sim_offset + i, p->max_rollout_plies, st));
+            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(bps * b->spec_k), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->seed,
+                                                  game_id_base, p->sim_offset, p->max_rollout_plies, bps, st));
         }
     }
     {
         SpanGuard sg(c, KC_MCTS_BACKUP);
-        DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, 1, 0, st));
+        DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, st));
     }
     HIPCHK(hipGetLastError());
     b->ran = true;
@@ -624,6 +642,7 @@ int tafl_mcts_get_stats(tafl_batch* b, tafl_mcts_stats* out) {
     memset(out, 0, sizeof *out);
     out->sims = h[ST_SIMS]; out->rollouts = h[ST_ROLLOUTS]; out->rollout_plies = h[ST_PLIES]; out->tree_depth_sum = h[ST_DEPTH];
     out->children_scanned = h[ST_SCANNED]; out->terminal_hits = h[ST_TERMINAL]; out->faults = h[ST_FAULTS];
+    out->spec_issued = h[ST_SPEC_ISSUED]; out->spec_hits = h[ST_SPEC_HITS];
     for (int i = 0; i < 16; ++i) out->reason_hist[i] = h[ST_REASON0 + i];
     return TAFL_OK;
 }

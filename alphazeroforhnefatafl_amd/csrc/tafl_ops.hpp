@@ -74,16 +74,30 @@ struct MctsMem {
     Edge* edges;                 // [g * edge_cap + e]
     uint32_t* node_top;          // [G]
     uint32_t* edge_top;          // [G]
-    uint32_t* leaf;              // [G] leaf of the running simulation
+    uint32_t* leaf;              // [G] leaf of the simulation whose playout value is pending
     uint8_t* kind;               // [G] 0 nothing pending, 1 rollout value pending, 2 terminal value pending
-    int8_t* rvalue;              // [G] playout value written by the rollout kernel
+    int8_t* rvalue;              // [G] playout value handed to the backup
     uint8_t* fault;              // [G]
-    uint32_t G, node_cap, edge_cap;
+    // ---- simulation pipeline (DESIGN.md "speculative playout slots") ------------------------------------------
+    uint32_t* sim_next;          // [G] simulations completed so far
+    Quad* spec_state;            // [(j * G + g) * QUADS] leaf state of slot j
+    int8_t* spec_value;          // [j * G + g] playout value of slot j
+    uint8_t* spec_kind;          // [j * G + g] 0 unused, 1 playout requested, 2 value ready, 3 no playout needed (terminal child)
+    uint8_t* spec_reason;        // [j * G + g] playout termination reason
+    uint32_t* spec_plies;        // [j * G + g] plies of the playout
+    uint32_t* spec_parent;       // [G] slot j is child (spec_o0 + j) of this node ...
+    int32_t* spec_o0;            // [G] ... -1: slot 0 is the (unexpanded) root itself
+    uint32_t* spec_first;        // [G] simulation index of slot 0
+    uint8_t* spec_n;             // [G] slots issued
+    uint32_t G, node_cap, edge_cap, spec_k;
 };
 
 struct LaneStats {
     uint32_t sims, rollouts, rollout_plies, depth, scanned, terminal_hits, faults;
     uint32_t reason;             // playout termination reason of this lane (valid when rollouts == 1)
+    uint64_t reason_hist4;       // tree phase: 16 x 4-bit counters of the termination reasons of the playouts CONSUMED by this lane
+                                 // (packed: a per-lane array indexed at run time would live in scratch)
+    uint32_t spec_issued, spec_hits;
 };
 
 #define TAFL_MCTS_EPS 1e-8       /* src/mcts.py:6 */
@@ -215,6 +229,8 @@ struct Ops {
         M.hdr[g] = h;
         IO::store_rec(M.node_state + (size_t)g * IO::QUADS, root);
         M.node_top[g] = 1; M.edge_top[g] = 0; M.leaf[g] = 0; M.kind[g] = 0; M.rvalue[g] = 0; M.fault[g] = 0;
+        M.sim_next[g] = 0; M.spec_n[g] = 0; M.spec_parent[g] = 0; M.spec_o0[g] = 0; M.spec_first[g] = 0;
+        for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;
     }
 
     // backup of the pending simulation (mcts.py:127-136 unwound iteratively)
@@ -305,15 +321,79 @@ struct Ops {
         M.fault[g] = 1; ls.faults += 1; M.kind[g] = 0;
     }
 
-    // playout for the pending leaf (predict() of mcts.py:85 in random-rollout mode)
-    static TAFL_HD void mcts_rollout(const MctsMem& M, uint32_t g, uint64_t seed, uint64_t game_id, uint32_t sim,
-                                     uint32_t max_plies, const K& C, LaneStats& ls) {
-        if (M.kind[g] != 1) return;
-        S st; IO::load_rec(M.node_state + ((size_t)M.leaf[g] * M.G + g) * IO::QUADS, st);
+    // ---- simulation pipeline ----------------------------------------------------------------------------------------
+    // One call advances game g by as many simulations as it can without waiting for a playout.  Every simulation does its
+    // real selection on the committed tree (mcts_select_expand); when that expands child `ord` of node P, the value of its
+    // playout is taken from a slot only if the slot was issued for exactly (P, ord, this simulation index) — the leaf
+    // state and the RNG key (game, sim) are then identical, so the value is the one a fresh playout would return.
+    // When no slot matches, the leaf becomes slot 0 and the next spec_k-1 slots are filled with the children
+    // ord+1, ord+2, ... of P for the following simulation indices: unvisited edges tie in PUCT and the lowest index wins
+    // (mcts.py:117-119), so unless a backed-up value lifts a visited child above them these are the next expansions.
+    static TAFL_HD void consume_stats(const MctsMem& M, uint32_t g, uint32_t j, LaneStats& ls) {
+        ls.rollouts += 1; ls.rollout_plies += M.spec_plies[(size_t)j * M.G + g]; ls.reason_hist4 += 1ull << (4u * (M.spec_reason[(size_t)j * M.G + g] & 15u));
+    }
+    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, const K& C, LaneStats& ls) {
+        uint32_t sim = M.sim_next[g];
+        if (M.kind[g] == 1) {                                    // slot 0 of the previous call: its playout has run
+            M.rvalue[g] = M.spec_value[g];
+            consume_stats(M, g, 0, ls);
+            mcts_backup(M, g); ++sim;
+        }
+        const uint32_t had = M.spec_n[g], first = M.spec_first[g], sparent = M.spec_parent[g];
+        const int32_t so0 = M.spec_o0[g];
+        for (;;) {
+            if (sim >= n_sims) { M.spec_n[g] = 0; break; }
+            mcts_select_expand(M, g, c_puct, C, ls);
+            const uint8_t kind = M.kind[g];
+            if (kind == 0) { ++sim; continue; }                                     // fault (flagged per game): nothing to back up
+            if (kind == 2) { mcts_backup(M, g); ++sim; continue; }                  // terminal node: value known at once
+            const uint32_t L = M.leaf[g];
+            uint32_t P = 0; int32_t ord = -1;
+            if (L != 0) { const NodeHdr lh = M.hdr[(size_t)L * M.G + g]; P = lh.parent; ord = (int32_t)lh.pslot; }
+            const uint32_t j = sim - first;
+            if (had > 0 && sim > first && j < had && sparent == P && so0 + (int32_t)j == ord && M.spec_kind[(size_t)j * M.G + g] == 2) {
+                M.rvalue[g] = M.spec_value[(size_t)j * M.G + g];                  // predicted expansion: reuse its playout
+                consume_stats(M, g, j, ls); ls.spec_hits += 1;
+                mcts_backup(M, g); ++sim;
+                continue;
+            }
+            // issue new slots: slot 0 = this leaf, slots 1.. = the next unvisited children of P
+            S lst; IO::load_rec(M.node_state + ((size_t)L * M.G + g) * IO::QUADS, lst);
+            IO::store_rec(M.spec_state + (size_t)g * IO::QUADS, lst);
+            M.spec_kind[g] = 1;
+            uint32_t cnt = 1;
+            const NodeHdr ph = M.hdr[(size_t)P * M.G + g];
+            if (M.spec_k > 1 && sim + 1 < n_sims) {
+                S pst; IO::load_rec(M.node_state + ((size_t)P * M.G + g) * IO::QUADS, pst);
+                Move cur; cur.from = ph.cur_from; cur.to = 0; cur.dir = ph.cur_dir; cur.dist = ph.cur_dist;
+                const uint32_t pside = pst.flags & TAFL_F_SIDE;
+                for (uint32_t t = 1; t < M.spec_k && sim + t < n_sims && (uint32_t)(ord + (int32_t)t) < ph.n_legal; ++t) {
+                    if (!E::canon_next(pst, pside, C, cur)) break;
+                    S cst = pst; Moves<NL> nx;
+                    E::apply(cst, cur, C, nullptr, nx);
+                    const bool term = TAFL_F_STATUS(cst.flags) != TAFL_STATUS_ONGOING;
+                    IO::store_rec(M.spec_state + ((size_t)t * M.G + g) * IO::QUADS, cst);
+                    M.spec_kind[(size_t)t * M.G + g] = term ? 3 : 1;
+                    if (!term) ls.spec_issued += 1;
+                    cnt = t + 1;
+                }
+            }
+            for (uint32_t t = cnt; t < M.spec_k; ++t) M.spec_kind[(size_t)t * M.G + g] = 0;
+            M.spec_n[g] = (uint8_t)cnt; M.spec_first[g] = sim; M.spec_parent[g] = P; M.spec_o0[g] = ord;
+            break;                                                                  // wait for the playouts
+        }
+        M.sim_next[g] = sim;
+    }
+
+    // playout of slot j of game g (predict() of mcts.py:85 in random-rollout mode)
+    static TAFL_HD void mcts_slot_rollout(const MctsMem& M, uint32_t j, uint32_t g, uint64_t seed, uint64_t game_id, uint32_t sim_offset,
+                                          uint32_t max_plies, const K& C) {
+        const size_t o = (size_t)j * M.G + g;
+        if (j >= M.spec_n[g] || M.spec_kind[o] != 1) return;
+        S st; IO::load_rec(M.spec_state + o * IO::QUADS, st);
         tafl_rollout_result r;
-        playout(st, E::sim_key(E::game_key(seed, game_id), sim), max_plies, C, r);
-        M.rvalue[g] = r.value;
-        ls.rollouts += 1; ls.rollout_plies += r.plies; ls.reason = r.reason;
+        playout(st, E::sim_key(E::game_key(seed, game_id), sim_offset + M.spec_first[g] + j), max_plies, C, r);
+        M.spec_value[o] = r.value; M.spec_reason[o] = r.reason; M.spec_plies[o] = r.plies; M.spec_kind[o] = 2;
     }
 
     // root statistics (mcts.py:40-41): visited root children in canonical order

@@ -121,8 +121,11 @@ def main():
     plies_per_step = float(stats.rollout_plies)
     total_plies = tdist.sum_over_ranks(plies_per_step, world, device="cuda") * args.steps
     if rank == 0:
-        avg_roll_s = (roll_ms / max(roll_n, 1)) * 1e-3
-        achieved = (ROLLOUT_BYTES_PER_GAME * G) / avg_roll_s / 1e9 if avg_roll_s > 0 else 0.0
+        # playouts actually executed by k_mcts_rollout in the last step: consumed ones + mispredicted speculative ones
+        executed = int(stats.rollouts - stats.spec_hits + stats.spec_issued)
+        roll_s_per_step = roll_ms * 1e-3 / args.steps
+        alg_bytes_per_step = ROLLOUT_BYTES_PER_GAME * executed
+        achieved = alg_bytes_per_step / roll_s_per_step / 1e9 if roll_s_per_step > 0 else 0.0
         d_bar = stats.tree_depth_sum / max(stats.sims, 1)
         c_bar = stats.children_scanned / max(stats.tree_depth_sum, 1)
         bytes_per_sim = d_bar * (64 + 16 * c_bar) + 32 + 2 * STATE_BYTES + 4     # SURVEY.md §8d formula
@@ -130,7 +133,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_k_mcts_rollout.json")
         if os.path.exists(tpath) and G == GAMES_PER_GPU:
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")      # rocprofv3 PMC pass of this same command (profiles/)
+                traffic = json.load(f).get("hbm_bytes_per_step")        # rocprofv3 PMC passes of this same command (profiles/)
         out = {
             "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -143,16 +146,17 @@ def main():
             "env_steps_per_sec": total_plies / elapsed,
             "plies_per_rollout": plies_per_step / max(stats.rollouts, 1),
             "mcts": {"sims": int(stats.sims), "rollouts": int(stats.rollouts), "terminal_hits": int(stats.terminal_hits),
-                     "mean_select_depth": d_bar, "mean_children_scanned": c_bar, "faults": int(stats.faults),
+                     "mean_select_depth": d_bar, "mean_children_scanned": c_bar, "faults": int(stats.faults), "spec_issued": int(stats.spec_issued), "spec_hits": int(stats.spec_hits),
                      "reason_hist": [int(x) for x in stats.reason_hist],
                      "algorithmic_bytes_per_sim": bytes_per_sim,
                      "hbm_frac_sims": (total_sims / elapsed / world) * bytes_per_sim / (HBM_PEAK_GBS * 1e9)},
-            "kernels_ms": {"k_mcts_rollout": {"avg": roll_ms / max(roll_n, 1), "launches": int(roll_n)},
-                           "k_mcts_tree": {"avg": tree_ms / max(tree_n, 1), "launches": int(tree_n)},
+            "kernels_ms": {"k_mcts_rollout": {"avg": roll_ms / max(roll_n, 1), "launches": int(roll_n), "total_per_step": roll_ms / args.steps},
+                           "k_mcts_tree": {"avg": tree_ms / max(tree_n, 1), "launches": int(tree_n), "total_per_step": tree_ms / args.steps},
                            "k_mcts_tree(final backup)": {"avg": bk_ms / max(bk_n, 1), "launches": int(bk_n)}},
             "roofline": {"kernel": "k_mcts_rollout", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ROLLOUT_BYTES_PER_GAME * G,
+                         "algorithmic_bytes": alg_bytes_per_step, "kernel_ms": roll_s_per_step * 1e3, "per": "step (all k_mcts_rollout launches)",
+                         "playouts_executed": executed,
                          "note": "register-resident playout: 68 algorithmic bytes per game per launch; the binding limit is "
                                  "integer VALU issue/latency, see DESIGN.md"},
         }

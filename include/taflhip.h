@@ -200,13 +200,15 @@ typedef struct tafl_mcts_params {
 
 typedef struct tafl_mcts_stats {
     uint64_t sims;             /* simulations executed (all games) */
-    uint64_t rollouts;         /* random playouts executed */
+    uint64_t rollouts;         /* random playouts consumed by simulations (mispredicted speculative ones excluded) */
     uint64_t rollout_plies;    /* env steps inside playouts */
     uint64_t tree_depth_sum;   /* sum over sims of nodes on the selection path (d) */
     uint64_t children_scanned; /* sum over sims of visited children examined (for c-bar) */
     uint64_t terminal_hits;    /* sims that ended on a terminal tree node */
     uint64_t reason_hist[16];  /* playout terminations by reason (win reasons 0-6, draws 8-9, cap 14, stuck 15) */
     uint64_t faults;           /* games that raised a device-side fault flag */
+    uint64_t spec_issued;      /* speculative playouts launched ahead of their simulation */
+    uint64_t spec_hits;        /* ... of which were consumed by the simulation they were predicted for */
 } tafl_mcts_stats;
 
 typedef struct tafl_ctx   tafl_ctx;    /* rules + geometry + device + stream */

@@ -11,6 +11,7 @@
 
 using namespace tafl;
 
+static uint32_t g_spec_k = 4;          // playout slots per game in the MCTS pipeline (1 = no speculation)
 static bool g_force_generic = false;   // differential tests: generic Engine::rollout vs the fast playout engine
 
 template <int NL, int W>
@@ -65,32 +66,38 @@ struct Host {
                     tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) {
         K C; if (consts(r, n, C)) return -1;
         using IO = StateIO<NL>;
-        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1);
-        std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS);
+        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k;
+        std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS), sst((size_t)M.spec_k * G * IO::QUADS);
         std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
         std::vector<Edge> edges((size_t)M.edge_cap * G);
-        std::vector<uint32_t> ntop(G), etop(G), leaf(G);
-        std::vector<uint8_t> kind(G), fault(G); std::vector<int8_t> rv(G);
+        std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sparent(G), sfirst(G), splies((size_t)M.spec_k * G);
+        std::vector<int32_t> so0(G);
+        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G);
+        std::vector<int8_t> rv(G), sval((size_t)M.spec_k * G);
         M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
         M.leaf = leaf.data(); M.kind = kind.data(); M.rvalue = rv.data(); M.fault = fault.data();
+        M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data();
+        M.spec_plies = splies.data(); M.spec_parent = sparent.data(); M.spec_o0 = so0.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; state_from_abi<NL>(st[g], s); O::mcts_init_game(M, g, s, C); }
-        for (uint32_t i = 0; i < p->n_sims; ++i) {
+        auto tree = [&]() {
             for (uint32_t g = 0; g < G; ++g) {
                 LaneStats ls; memset(&ls, 0, sizeof ls);
-                O::mcts_backup(M, g);
-                O::mcts_select_expand(M, g, p->c_puct, C, ls);
+                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, C, ls);
                 stats->sims += ls.sims; stats->tree_depth_sum += ls.depth; stats->children_scanned += ls.scanned;
                 stats->terminal_hits += ls.terminal_hits; stats->faults += ls.faults;
-            }
-            for (uint32_t g = 0; g < G; ++g) {
-                LaneStats ls; memset(&ls, 0, sizeof ls);
-                O::mcts_rollout(M, g, p->seed, base + g, p->sim_offset + i, p->max_rollout_plies, C, ls);
                 stats->rollouts += ls.rollouts; stats->rollout_plies += ls.rollout_plies;
-                if (ls.rollouts) stats->reason_hist[ls.reason & 15]++;
+                for (int q = 0; q < 16; ++q) stats->reason_hist[q] += (ls.reason_hist4 >> (4 * q)) & 15u;
+                stats->spec_issued += ls.spec_issued; stats->spec_hits += ls.spec_hits;
             }
+        };
+        for (uint32_t i = 0; i < p->n_sims; ++i) {
+            tree();
+            for (uint32_t j = 0; j < M.spec_k; ++j)
+                for (uint32_t g = 0; g < G; ++g) O::mcts_slot_rollout(M, j, g, p->seed, base + g, p->sim_offset, p->max_rollout_plies, C);
         }
-        for (uint32_t g = 0; g < G; ++g) O::mcts_backup(M, g);
+        tree();
+        for (uint32_t g = 0; g < G; ++g) if (simn[g] != p->n_sims) return -3;
         for (uint32_t g = 0; g < G; ++g) {
             const uint32_t k = O::mcts_root_children(M, g, C, out_children + (size_t)g * max_children, max_children);
             if (out_n) out_n[g] = k;
@@ -109,6 +116,7 @@ struct Host {
 
 extern "C" {
 void hs_force_generic(int on) { g_force_generic = on != 0; }
+void hs_set_spec_k(uint32_t k) { g_spec_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
 int hs_movegen(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint32_t* counts, uint32_t* masks, uint32_t mw) { DISPATCH(movegen(r, n, st, cnt, counts, masks, mw)) }
 int hs_validate(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_play* plays, uint8_t* codes) { DISPATCH(validate(r, n, st, cnt, plays, codes)) }
 int hs_step(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const tafl_play* plays, tafl_effects* eff) { DISPATCH(step(r, n, st, cnt, plays, eff)) }

@@ -138,3 +138,49 @@ def test_mcts(name, sims, cpuct):
     for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
         assert getattr(ostats, f) == getattr(hstats, f), f
     assert list(ostats.reason_hist) == list(hstats.reason_hist)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 8])
+def test_mcts_speculative_slots_do_not_change_results(k):
+    """The MCTS pipeline with k playout slots per game (k-1 speculative) must reproduce the sequential search exactly:
+    root statistics as float64 bit patterns and every counter, for start, mid-game and terminal-heavy positions."""
+    import json
+    import os
+    from tests.hostsim import hostsim
+    hostsim.set_spec_k(k)
+    try:
+        gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mcts_golden.json")))
+        for case in gold["cases"]:
+            if case["n_sims"] > 300:
+                continue
+            rules = abi.rules.BY_NAME[case["rules"]]
+            st = abi.TaflState.from_buffer_copy(bytes.fromhex(case["state_hex"]))
+            hs = HostSim(rules, case["side_len"], case["word_bits"])
+            arr = (abi.TaflState * 2)(st, st)
+            p = TaflMctsParams(case["n_sims"], case["max_plies"], case["cpuct"], case["seed"], 0, 0)
+            kids, cnt, stats = hs.mcts(arr, 2, p, case["game_id"])
+            got = [[kids[j].action, kids[j].visits, float(kids[j].q).hex()] for j in range(cnt[0])]
+            assert got == case["root_children"], (k, case["name"])
+            assert stats.faults == 0 and stats.sims == 2 * case["n_sims"]
+            if k == 1:
+                assert stats.spec_issued == 0 and stats.spec_hits == 0
+        # terminal-heavy synthetic positions against the oracle, incl. all counters
+        rng = random.Random(5)
+        n, wb = 7, 64
+        lst = pu.sparse_endgame_positions(rng, n, wb, 40)
+        states = pu.states_array(lst)
+        lg, hs = orc.GameLogic(abi.rules.BRANDUBH, n), HostSim(abi.rules.BRANDUBH, n, wb)
+        p = TaflMctsParams(60, 40, 1.0, 3, 0, 0)
+        ok, on, ostats = orc.batch_mcts(lg, states, 40, wb, p, 5)
+        hk, hn, hstats = hs.mcts(states, 40, p, 5)
+        assert list(on) == list(hn)
+        for g in range(40):
+            for j in range(on[g]):
+                a, b = ok[g * 256 + j], hk[g * 256 + j]
+                assert (a.action, a.visits, float(a.q).hex()) == (b.action, b.visits, float(b.q).hex()), (k, g, j)
+        for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+            assert getattr(ostats, f) == getattr(hstats, f), (k, f)
+        assert list(ostats.reason_hist) == list(hstats.reason_hist)
+        assert ostats.terminal_hits > 0
+    finally:
+        hostsim.set_spec_k(4)
