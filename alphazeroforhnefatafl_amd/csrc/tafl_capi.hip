@@ -27,6 +27,12 @@ using namespace tafl;
 #ifndef TAFL_KATTR
 #define TAFL_KATTR
 #endif
+// the MCTS pipeline runs spec_k (default 2) playout waves per SIMD.  Measured on MI355X: a SIMD issues one of these integer
+// wave-instructions per 4 cycles and a single playout wave already reaches ~65 % of that; the second wave fills most of the
+// rest (+18 %), more waves add nothing.
+#ifndef TAFL_ROLLOUT_WAVES
+#define TAFL_ROLLOUT_WAVES 2
+#endif
 
 template <int NL, int W>
 __global__ __launch_bounds__(TAFL_BLOCK) void k_fill(Quad* soa, uint32_t n, DState<NL> st) {
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
 // the dominant kernel: one seeded random playout per (slot, game), state resident in registers.  Slot-major grid: block b
 // serves slot b / blocks_per_slot, so spec_k slots per game put up to spec_k waves on every SIMD.
 template <int NL, int W, int PRESET>
-__global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim_offset,
+__global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim_offset,
                                                                        uint32_t max_plies, uint32_t blocks_per_slot, unsigned long long* stats) {
     const uint32_t j = blockIdx.x / blocks_per_slot;
     const uint32_t g = (blockIdx.x % blocks_per_slot) * TAFL_BLOCK + threadIdx.x;
@@ -369,7 +375,7 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     tafl_batch* b = new (std::nothrow) tafl_batch();
     if (!b) return fail(TAFL_ERR_OOM, "out of host memory");
     b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr;
-    { const char* e = getenv("TAFL_SPEC_K"); int k = e ? atoi(e) : 4; b->spec_k = (uint32_t)(k < 1 ? 1 : (k > 8 ? 8 : k)); }
+    { const char* e = getenv("TAFL_SPEC_K"); int k = e ? atoi(e) : 2; b->spec_k = (uint32_t)(k < 1 ? 1 : (k > 8 ? 8 : k)); }
     memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats);
     const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
     if (hipMalloc((void**)&b->soa, bytes) != hipSuccess) { delete b; return fail(TAFL_ERR_OOM, "hipMalloc(batch states) failed"); }

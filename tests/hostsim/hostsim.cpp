@@ -11,7 +11,7 @@
 
 using namespace tafl;
 
-static uint32_t g_spec_k = 4;          // playout slots per game in the MCTS pipeline (1 = no speculation)
+static uint32_t g_spec_k = 2;          // playout slots per game in the MCTS pipeline (1 = no speculation)
 static bool g_force_generic = false;   // differential tests: generic Engine::rollout vs the fast playout engine
 
 template <int NL, int W>

@@ -183,4 +183,4 @@ def test_mcts_speculative_slots_do_not_change_results(k):
         assert list(ostats.reason_hist) == list(hstats.reason_hist)
         assert ostats.terminal_hits > 0
     finally:
-        hostsim.set_spec_k(4)
+        hostsim.set_spec_k(2)
