@@ -22,6 +22,16 @@
 
 namespace tafl {
 
+// true if the predicate holds for ANY game of the wavefront (device) / for this game (host build): used to skip work that
+// no game of the wave needs; results never depend on it.
+TAFL_HD bool wave_any(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(p) != 0ull;
+#else
+    return p;
+#endif
+}
+
 template <int NL>
 struct Bits {
     uint32_t w[NL];

@@ -111,11 +111,13 @@ struct Fast {
         // soldiers and king separately: they differ only in the tiles they may stop on (pieces of either kind block alike)
         return andn(fill(occ, andn(mine, kbit), vblock) & open, lfs) | andn(fill(occ, kbit, vblock) & open, lfk);
     }
-    static TAFL_HD void gen(const S& st, const B& attT, const B& defT, uint32_t side, const K& C, const F& fc, bool any_king_lane, Gen& g) {
+    static TAFL_HD void gen(const S& st, const B& attT, const B& defT, uint32_t side, const K& C, const F& fc, Gen& g) {
         const B occN = (st.att | st.def) & C.board, occT = (attT | defT) & C.board;
         const B mineN = (side ? st.def : st.att) & C.board, mineT = (side ? defT : attT) & C.board;
         const uint32_t k = E::king_sq(st, C);
         B kN = bz<NL>(), kT = bz<NL>();
+        // the king's own rays are needed only where a defender is to move: skipped when no game of the wave is in that case
+        const bool any_king_lane = wave_any(side != 0 && k != TAFL_NO_SQ);
         if (any_king_lane) {
             const bool kalive = side && k != TAFL_NO_SQ;
             const uint32_t ks = kalive ? k : 0u;
@@ -165,7 +167,7 @@ struct Fast {
         B attT, defT;
         transpose_in(st.att & C.board, attT); transpose_in(st.def & C.board, defT);
         Gen g;
-        if (TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) gen(st, attT, defT, start_side, C, fc, true, g);
+        if (TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) gen(st, attT, defT, start_side, C, fc, g);
         else { TAFL_UNROLL for (int d = 0; d < 4; ++d) { g.r[d] = bz<NL>(); g.cnt[d] = 0; } g.total = 0; g.edge_hit = false; }
         uint32_t ply = 0; bool stuck = false;
         while (ply < max_plies && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
@@ -195,7 +197,7 @@ struct Fast {
                 while (any(c)) { const uint32_t i = lsb(c); c = andn(c, bit_at<NL>(i)); const B cb = bit_at<NL>(n_to_t(i)); attT = andn(attT, cb); defT = andn(defT, cb); }
             }
             // opponent's plays on the post-move board: no-plays test, enclosure filter, and the next ply's move set
-            gen(st, attT, defT, ax.mover ^ 1u, C, fc, true, g);
+            gen(st, attT, defT, ax.mover ^ 1u, C, fc, g);
             const bool skip_encl = ax.mover == 0 && C.rules.enclosure_win == TAFL_ENCL_WITHOUT_EDGE_ACCESS
                                    && (g.edge_hit || any(st.def & C.edge));
             const typename E::Outcome o = E::outcome_early(st, ax, C, skip_encl);
