@@ -157,8 +157,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes_per_step, "kernel_ms": roll_s_per_step * 1e3, "per": "step (all k_mcts_rollout launches)",
                          "playouts_executed": executed,
-                         "note": "register-resident playout: 68 algorithmic bytes per game per launch; the binding limit is "
-                                 "integer VALU issue/latency, see DESIGN.md"},
+                         "note": "register-resident playout: 68 algorithmic bytes per playout; the binding limit is integer VALU issue "
+                                 "(79 % of the measured 1-instruction-per-4-cycles-per-SIMD peak, profiles/r01_v6_pipeline), see DESIGN.md section 6"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpuct, args.seed, args.max_plies)
