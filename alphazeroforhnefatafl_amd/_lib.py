@@ -49,6 +49,8 @@ SYMBOLS = [
     ("tafl_mcts_root_visits", _i32, [_vp, _P(_u32)]),
     ("tafl_mcts_policy", _i32, [_vp, _dbl, _P(_dbl)]),
     ("tafl_mcts_best_play", _i32, [_vp, _P(TaflPlay), _P(_u32)]),
+    ("tafl_encode_boards", _i32, [_vp, _vp, _i32]),
+    ("tafl_mcts_policy_device", _i32, [_vp, _dbl, _vp, _i32]),
     ("tafl_timing_enable", _i32, [_vp, _i32]),
     ("tafl_timing_reset", _i32, [_vp]),
     ("tafl_timing_get", _i32, [_vp, _i32, _P(_dbl), _P(_u64)]),

@@ -192,6 +192,66 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_root_visits(Consts<NL> C, M
     }
 }
 
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_best_play(Consts<NL> C, MctsMem M, tafl_play* out_plays, uint32_t* out_visits) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    const NodeHdr h = M.hdr[g];
+    const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+    uint32_t best = 0; tafl_play bp; bp.from_row = bp.from_col = bp.axis = 0; bp.disp = 0;
+    for (uint32_t j = 0; j < h.m; ++j) {                       // first maximum (src/mcts.rs:216-227)
+        const Edge e = eb[j];
+        if (e.n > best) {
+            const NodeHdr ch = M.hdr[(size_t)e.child * M.G + g];
+            Move m; m.from = ch.mv_from; m.dir = ch.mv_dir; m.dist = ch.mv_dist; m.to = 0;
+            best = e.n; bp = Ops<NL, W>::to_play(m);
+        }
+    }
+    out_plays[g] = bp; out_visits[g] = best;
+}
+
+// board_to_matrix (game/main.rs:55-83): corners 20, throne 30, soldier +1, king +5, one uint8 per tile, row-major n x n.
+// One lane per tile: consecutive lanes write consecutive bytes.
+template <int NL, int W>
+__global__ __launch_bounds__(256) void k_encode_boards(Consts<NL> C, const Quad* soa, uint32_t n_games, uint8_t* out) {
+    const uint32_t nn = C.n * C.n;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n_games * nn) return;
+    const uint32_t g = (uint32_t)(i / nn), t = (uint32_t)(i % nn), r = t / C.n, c = t % C.n, bit = r * (uint32_t)W + c;
+    const uint32_t wa = bit >> 5, wd = (uint32_t)NL + (bit >> 5);         // absolute state words: att[NL], def[NL], rep[4], meta[4]
+    const Quad qa = soa[(size_t)(wa >> 2) * n_games + g], qd = soa[(size_t)(wd >> 2) * n_games + g];
+    const uint32_t la = wa & 3, ld = wd & 3;
+    const uint32_t aw = la == 0 ? qa.x : la == 1 ? qa.y : la == 2 ? qa.z : qa.w;
+    const uint32_t dw = ld == 0 ? qd.x : ld == 1 ? qd.y : ld == 2 ? qd.z : qd.w;
+    const Quad meta = soa[(size_t)(2 * NL + 4) / 4 * n_games + g];
+    const uint32_t flags = meta.w, krow = TAFL_F_KROW(flags), kcol = TAFL_F_KCOL(flags);
+    uint32_t v = 0;
+    if ((r == 0 || r == C.n - 1) && (c == 0 || c == C.n - 1)) v = 20;
+    if (r == C.n / 2 && c == C.n / 2) v = 30;
+    const bool d = (dw >> (bit & 31)) & 1u, a = (aw >> (bit & 31)) & 1u;
+    if (d) v += (r == krow && c == kcol) ? 5u : 1u; else if (a) v += 1u;
+    out[i] = (uint8_t)v;
+}
+
+// probs of src/mcts.py:48-53 at temp == 1 (counts / float(sum(counts)), exact in float64) or temp == 0 (one-hot on the first maximum)
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_policy(Consts<NL> C, MctsMem M, double* out, uint32_t action_size, int one_hot) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    const NodeHdr h = M.hdr[g];
+    const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+    double sum = 0.0; uint32_t best = 0, arg = 0;
+    for (uint32_t j = 0; j < h.m; ++j) { const Edge e = eb[j]; sum += (double)e.n; if (e.n > best) { best = e.n; arg = j; } }
+    for (uint32_t j = 0; j < h.m; ++j) {
+        const Edge e = eb[j];
+        const NodeHdr ch = M.hdr[(size_t)e.child * M.G + g];
+        Move m; m.from = ch.mv_from; m.dir = ch.mv_dir; m.dist = ch.mv_dist; m.to = 0;
+        const double p = one_hot ? ((j == arg && best > 0) ? 1.0 : 0.0) : (double)e.n / sum;
+        out[(size_t)g * action_size + Ops<NL, W>::action_of(m, C)] = p;
+    }
+    if (one_hot && best == 0) out[(size_t)g * action_size] = 1.0;          // all counts zero: argmax of zeros = action 0 (np.argwhere order)
+}
+
 // --------------------------------------------------------------------------------------------------
 // host objects
 // --------------------------------------------------------------------------------------------------
@@ -236,6 +296,7 @@ struct tafl_batch {
     // MCTS
     MctsMem mem; bool has_mem; uint32_t reserved_sims;
     DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, rvalue, fault, stats, children, children_n, visits;
+    DevBuf best_plays, best_visits, enc, policy;
     DevBuf sim_next, spec_state, spec_value, spec_kind, spec_reason, spec_plies, spec_parent, spec_o0, spec_first, spec_n;
     uint32_t spec_k;
     tafl_mcts_stats last_stats; bool ran;
@@ -392,7 +453,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n};
+                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n, &b->best_plays, &b->best_visits, &b->enc, &b->policy};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return TAFL_OK;
@@ -707,15 +768,44 @@ int tafl_mcts_policy(tafl_batch* b, double temp, double* out) {
 
 int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visits) {
     if (!b || !out_plays || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
-    const uint32_t n = b->n, mc = 2u * (b->ctx->n - 1) * 40u;
-    std::vector<tafl_root_child> kids((size_t)n * mc); std::vector<uint32_t> cnt(n);
-    int rc = tafl_mcts_root_children(b, kids.data(), mc, cnt.data());
-    if (rc) return rc;
-    for (uint32_t g = 0; g < n; ++g) {
-        uint32_t best = 0; tafl_play bp; memset(&bp, 0, sizeof bp);
-        for (uint32_t j = 0; j < cnt[g]; ++j) { const tafl_root_child& k = kids[(size_t)g * mc + j]; if (k.visits > best) { best = k.visits; bp = k.play; } }
-        out_plays[g] = bp; if (out_visits) out_visits[g] = best;
-    }
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->best_plays, sizeof(tafl_play) * n); NEED(b->best_visits, sizeof(uint32_t) * n);
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_best_play<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem,
+                                       (tafl_play*)b->best_plays.p, (uint32_t*)b->best_visits.p));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_plays, b->best_plays.p, sizeof(tafl_play) * n, hipMemcpyDeviceToHost, c->stream));
+    if (out_visits) HIPCHK(hipMemcpyAsync(out_visits, b->best_visits.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+// ---- training-tensor writers: outputs may be HOST or DEVICE pointers --------------------
+int tafl_encode_boards(tafl_batch* b, uint8_t* out, int out_is_device) {
+    if (!b || !out) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n; const size_t total = (size_t)n * c->n * c->n;
+    HIPCHK(hipSetDevice(c->device));
+    uint8_t* dst = out;
+    if (!out_is_device) { NEED(b->enc, total); dst = (uint8_t*)b->enc.p; }
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_encode_boards<NL, W>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, CC, b->soa, n, dst));
+    HIPCHK(hipGetLastError());
+    if (!out_is_device) HIPCHK(hipMemcpyAsync(out, dst, total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_device) {
+    if (!b || !out || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!(temp == 0.0 || temp == 1.0)) return fail(TAFL_ERR_UNSUPPORTED, "device policy writer supports temp 0 and 1 (use tafl_mcts_policy for other temperatures)");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n, as = tafl_action_size(c); const size_t bytes = sizeof(double) * (size_t)n * as;
+    HIPCHK(hipSetDevice(c->device));
+    double* dst = out;
+    if (!out_is_device) { NEED(b->policy, bytes); dst = (double*)b->policy.p; }
+    HIPCHK(hipMemsetAsync(dst, 0, bytes, c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_policy<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, dst, as, temp == 0.0 ? 1 : 0));
+    HIPCHK(hipGetLastError());
+    if (!out_is_device) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return TAFL_OK;
 }
 

@@ -185,6 +185,25 @@ class GameBatch:
         check(lib().tafl_mcts_policy(self._h, temp, out))
         return out
 
+    def encode_boards(self, out_device_ptr: int | None = None):
+        """board_to_matrix (game/main.rs:55-83) for every game: uint8 [n, side_len, side_len].  With `out_device_ptr`
+        (e.g. a torch uint8 tensor's data_ptr on this device) nothing crosses PCIe; otherwise returns a host ctypes array."""
+        if out_device_ptr is not None:
+            check(lib().tafl_encode_boards(self._h, C.c_void_p(out_device_ptr), 1))
+            return None
+        out = (C.c_uint8 * (self.n * self.logic.side_len * self.logic.side_len))()
+        check(lib().tafl_encode_boards(self._h, C.cast(out, C.c_void_p), 0))
+        return out
+
+    def mcts_policy_device(self, temp: float = 1.0, out_device_ptr: int | None = None):
+        """src/mcts.py:40-53 written by a kernel (temp 0 or 1); float64 [n, action_size]."""
+        if out_device_ptr is not None:
+            check(lib().tafl_mcts_policy_device(self._h, temp, C.c_void_p(out_device_ptr), 1))
+            return None
+        out = (C.c_double * (self.n * self.logic.action_size))()
+        check(lib().tafl_mcts_policy_device(self._h, temp, C.cast(out, C.c_void_p), 0))
+        return out
+
     def mcts_best_play(self):
         plays = (TaflPlay * self.n)()
         visits = (C.c_uint32 * self.n)()

@@ -304,6 +304,16 @@ int tafl_mcts_root_visits(tafl_batch* b, uint32_t* out);
 int tafl_mcts_policy(tafl_batch* b, double temp, double* out);
 int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visits);
 
+/* ---- training-tensor writers (the step right after the hot path) ------------------------------
+ * tafl_encode_boards: board_to_matrix (game/main.rs:55-83) for every game: uint8 [n * side_len * side_len], row-major;
+ *   corner tiles 20, throne 30, soldier +1, king +5 (no side distinction, as in the reference).
+ * tafl_mcts_policy_device: the probs of src/mcts.py:40-53 written by a kernel, for temp == 1 (counts / sum, exact) or
+ *   temp == 0 (one-hot on the first maximum); float64 [n * tafl_action_size].
+ * `out` may be a host pointer (out_is_device = 0) or a device pointer of this ctx's device (out_is_device = 1, e.g. a
+ * torch tensor's data_ptr): the second form never crosses PCIe. */
+int tafl_encode_boards(tafl_batch* b, uint8_t* out, int out_is_device);
+int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_device);
+
 /* ---- measurement helpers (bench.py) -----------------------------------------------------------------
  * HIP-event timing on the ctx stream: average duration of the named kernel class since the last reset.
  * classes: 0 movegen, 1 step, 2 rollout, 3 mcts_select_expand, 4 mcts_rollout, 5 mcts_backup */

@@ -62,6 +62,7 @@ def lib():
         sig("orc_iter_occupied", i32, vp, u8, P(u8), i32)
         sig("orc_to_fen", i32, vp, C.c_char_p, i32)
         sig("orc_from_display_str", i32, vp, C.c_char_p, u32)
+        sig("orc_board_to_matrix", i32, vp, P(u8))
         sig("orc_neighbors", i32, vp, u8, u8, P(u8))
         sig("orc_tiles_between", i32, vp, u8, u8, u8, u8, P(u8))
         sig("orc_validate_play", i32, vp, vp, TaflPlay)
@@ -340,6 +341,13 @@ class GameState:
         buf = (C.c_uint8 * 1024)()
         n = lib().orc_iter_occupied(self.ptr, side, buf, 512)
         return _rc_list(buf, n)
+
+    def board_to_matrix(self):
+        """game/main.rs:55-83: n x n uint8 rows (corner 20, throne 30, soldier +1, king +5)."""
+        n = self.to_abi().side_len if self.word_bits <= 256 else 0
+        buf = (C.c_uint8 * (n * n))()
+        lib().orc_board_to_matrix(self.ptr, buf)
+        return [list(buf[r * n:(r + 1) * n]) for r in range(n)]
 
     def to_fen(self) -> str:
         buf = C.create_string_buffer(1024)

@@ -92,6 +92,7 @@ int  orc_count_pieces(const ostate* st, uint8_t side);
 int  orc_iter_occupied(const ostate* st, uint8_t side, uint8_t* out_rc, int cap);
 int  orc_to_fen(const ostate* st, char* out, int cap);
 int  orc_from_display_str(ostate* st, const char* s, uint32_t word_bits);
+int  orc_board_to_matrix(const ostate* st, uint8_t* out);                 /* game/main.rs:55-83 */
 
 /* --- geometry (game/board/geometry.rs) -------------------------------------------------------- */
 int orc_neighbors(const ologic* lg, uint8_t row, uint8_t col, uint8_t* out_rc);

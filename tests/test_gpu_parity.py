@@ -435,3 +435,43 @@ def test_full_size_properties_65536():
     oneres = orc.batch_rollout(lg, one, 1, wb, 7, 0, 512, 4097)
     assert (oneres[0].value, oneres[0].reason, oneres[0].plies) == (res[4097].value, res[4097].reason, res[4097].plies)
     assert pu.states_equal(pu.start_states(orc, fen, rules.starting_side, wb, 64), big.download(0, 64), 64)
+
+
+def test_training_tensor_writers():
+    """board_to_matrix (game/main.rs:55-83) and the policy targets of src/mcts.py:40-53 written on the device,
+    to host buffers and straight into torch tensors (device pointers)."""
+    import torch
+    rng = random.Random(17)
+    for name in ("copenhagen11", "brandubh7", "copenhagen13", "tablut9"):
+        rules, fen, wb, n, lg = _mk(name)
+        G = 300
+        states = pu.random_board_states(rng, n, wb, G)
+        b = gpu_batch(rules, n, wb, states, G)
+        enc = b.encode_boards()
+        t = torch.zeros((G, n, n), dtype=torch.uint8, device="cuda")
+        b.encode_boards(out_device_ptr=t.data_ptr())
+        tl = t.cpu().flatten().tolist()
+        assert tl == list(enc), name
+        for g in range(0, G, 11):
+            want = orc.GameState.from_abi(states[g], wb).board_to_matrix()
+            got = [list(enc[g * n * n + r * n:g * n * n + (r + 1) * n]) for r in range(n)]
+            assert got == want, (name, g)
+    # policy targets
+    rules, fen, wb, n, lg = _mk("copenhagen11")
+    G = 128
+    b = gpu_logic(rules, n, wb).new_batch(G, fen)
+    b.mcts_run(32, 1.0, 5, 128, game_id_base=3)
+    host = b.mcts_policy(1.0)
+    dev = b.mcts_policy_device(1.0)
+    assert bytes(host) == bytes(dev)
+    A = b.logic.action_size
+    t = torch.zeros((G, A), dtype=torch.float64, device="cuda")
+    b.mcts_policy_device(1.0, out_device_ptr=t.data_ptr())
+    assert t.cpu().flatten().tolist() == list(host)
+    assert bytes(b.mcts_policy(0.0)) == bytes(b.mcts_policy_device(0.0))
+    # best play = first maximum of the root visit counts
+    bp, bv = b.mcts_best_play()
+    kids, cnt = b.mcts_root_children(256)
+    for g in range(G):
+        vs = [kids[g * 256 + j].visits for j in range(cnt[g])]
+        assert bv[g] == max(vs) and pu.play_tuple4(bp[g]) == pu.play_tuple4(kids[g * 256 + vs.index(max(vs))].play)
