@@ -40,15 +40,32 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_fill(Quad* soa, uint32_t n, DSta
     if (g < n) StateIO<NL>::store_soa(soa, n, g, st);
 }
 
+// counts only: one game per lane
 template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_movegen(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t* counts, uint32_t* masks, uint32_t mw) {
+__global__ __launch_bounds__(TAFL_BLOCK) void k_movegen(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t* counts) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= n) return;
     DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
-    uint32_t* m = masks ? masks + (size_t)g * mw : nullptr;
-    if (m) for (uint32_t i = 0; i < mw; ++i) m[i] = 0;
-    const uint32_t c = Ops<NL, W>::movegen(st, C, m);
-    if (counts) counts[g] = c;
+    counts[g] = Ops<NL, W>::movegen(st, C, nullptr);
+}
+
+// counts + dense action masks: each lane builds its game's mask in LDS (ds_or, no global read-modify-write), then the
+// workgroup streams the 64 masks out as one contiguous block (64 x mask_words uint32, fully coalesced).
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_movegen_masks(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t* counts, uint32_t* masks, uint32_t mw) {
+    extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw]
+    const uint32_t g0 = blockIdx.x * TAFL_BLOCK, g = g0 + threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * mw; i += TAFL_BLOCK) lds_masks[i] = 0;
+    __syncthreads();
+    if (g < n) {
+        DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+        const uint32_t c = Ops<NL, W>::movegen(st, C, lds_masks + (size_t)threadIdx.x * mw);
+        if (counts) counts[g] = c;
+    }
+    __syncthreads();
+    const uint32_t games = (n - g0) < TAFL_BLOCK ? (n - g0) : TAFL_BLOCK;
+    uint32_t* dst = masks + (size_t)g0 * mw;
+    for (uint32_t i = threadIdx.x; i < games * mw; i += TAFL_BLOCK) dst[i] = lds_masks[i];
 }
 
 template <int NL, int W>
@@ -529,8 +546,12 @@ int tafl_movegen(tafl_batch* b, uint32_t* out_counts, uint32_t* out_masks) {
     if (out_masks) NEED(b->masks, sizeof(uint32_t) * (size_t)n * mw);
     {
         SpanGuard sg(c, KC_MOVEGEN);
-        DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
-                                           (uint32_t*)b->counts.p, out_masks ? (uint32_t*)b->masks.p : nullptr, mw));
+        if (out_masks) {
+            DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen_masks<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), TAFL_BLOCK * mw * sizeof(uint32_t), c->stream,
+                                               CC, b->soa, n, (uint32_t*)b->counts.p, (uint32_t*)b->masks.p, mw));
+        } else {
+            DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, (uint32_t*)b->counts.p));
+        }
     }
     HIPCHK(hipGetLastError());
     if (out_counts) HIPCHK(hipMemcpyAsync(out_counts, b->counts.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
