@@ -164,13 +164,23 @@ struct Engine {
 
     static TAFL_HD int delta(uint32_t dir) { return dir == 0 ? W : dir == 1 ? -W : dir == 2 ? 1 : -1; }
 
-    // the piece that reaches `to` moving in `dir`: nearest occupied tile behind `to`
-    static TAFL_HD Move resolve(const S& st, uint32_t dir, uint32_t to) {
-        const B occ = st.att | st.def;
-        const int dl = delta(dir);
-        int sq = (int)to; uint32_t dist = 0;
-        do { sq -= dl; ++dist; } while (dist < 32 && !test(occ, (uint32_t)sq));
-        Move m; m.from = (uint32_t)sq; m.to = to; m.dir = dir; m.dist = dist;
+    // column `c` of the board as a mask (col0 pattern moved c < W <= 15 bits up: at most one limb of carry)
+    static TAFL_HD B col_mask(uint32_t c, const K& C) {
+        B o;
+        TAFL_UNROLL for (int i = 0; i < NL; ++i) o.w[i] = (C.col0.w[i] << c) | ((c != 0 && i > 0) ? (C.col0.w[i > 0 ? i - 1 : 0] >> ((32 - c) & 31)) : 0u);
+        return o;
+    }
+    // the piece that reaches `to` moving in `dir`: the nearest occupied tile behind `to` on its line (no loop: highest /
+    // lowest occupied bit of the line segment behind the destination)
+    static TAFL_HD Move resolve(const S& st, uint32_t dir, uint32_t to, const K& C) {
+        const B occ = (st.att | st.def) & C.board;
+        const B lo = below<NL>(to), hi = andn(C.board, below<NL>(to + 1));
+        uint32_t from;
+        if (dir >= 2) from = (dir == 2) ? msb(occ & lo) : lsb(occ & hi);                      // same row: bits are contiguous
+        else { const B col = occ & col_mask(to % (uint32_t)W, C); from = (dir == 0) ? msb(col & lo) : lsb(col & hi); }
+        Move m; m.from = from; m.to = to; m.dir = dir;
+        const uint32_t d = to > from ? to - from : from - to;
+        m.dist = dir >= 2 ? d : d / (uint32_t)W;
         return m;
     }
     // idx-th play in ROLLOUT ORDER [build-defined, DESIGN.md]: direction-major V+,V-,H+,H-; inside a direction the
@@ -180,9 +190,7 @@ struct Engine {
     static TAFL_HD uint32_t nth_colmajor(const B& r, uint32_t j, const K& C) {
         uint32_t res = 0; bool found = false;
         for (uint32_t c = 0; c < C.n; ++c) {
-            B colm = bz<NL>();
-            // column c = col0 pattern moved right by c (c < W <= 15: at most one limb of carry)
-            TAFL_UNROLL for (int i = 0; i < NL; ++i) colm.w[i] = (C.col0.w[i] << c) | ((c && i > 0) ? (C.col0.w[i - 1] >> (32 - c)) : 0u);
+            const B colm = col_mask(c, C);
             const B rc = r & colm;
             const uint32_t k = popc(rc);
             if (!found) { if (j < k) { res = nth_set_bit(rc, j); found = true; } else j -= k; }
@@ -199,7 +207,7 @@ struct Engine {
         else if (dir == 1) to = nth_colmajor(mv.reach[1], mv.cnt[1] - 1 - idx, C);
         else if (dir == 2) to = nth_set_bit(mv.reach[2], idx);
         else to = nth_set_bit(mv.reach[3], mv.cnt[3] - 1 - idx);
-        return resolve(st, dir, to);
+        return resolve(st, dir, to, C);
     }
 
     // ---- canonical iteration (ValidPlayIterator order: play.rs:157,166-183 over iter_occupied) -------------

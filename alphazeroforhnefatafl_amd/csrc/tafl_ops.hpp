@@ -144,7 +144,7 @@ struct Ops {
                 while (any(r)) {
                     const uint32_t to = lsb(r);
                     r = andn(r, bit_at<NL>(to));
-                    const Move m = E::resolve(st, (uint32_t)d, to);
+                    const Move m = E::resolve(st, (uint32_t)d, to, C);
                     const uint32_t a = action_of(m, C);
                     if (a < C.n * C.n * 2u * (C.n - 1)) mask[a >> 5] |= 1u << (a & 31);   // never write outside the game's mask
                 }
