@@ -148,12 +148,13 @@ template <int NL> TAFL_HD uint32_t window5(const Bits<NL>& a, uint32_t idx) {
     const Bits<NL> b = shl<2>(a);                      // bit (idx-2) of a is bit idx of b: no negative positions
     const uint32_t wi = idx >> 5, off = idx & 31;
     uint32_t lo = 0, hi = 0;
-    TAFL_UNROLL for (int i = 0; i < NL; ++i) {
-        const uint32_t ml = ((uint32_t)i == wi) ? 0xFFFFFFFFu : 0u, mh = ((uint32_t)i == wi + 1) ? 0xFFFFFFFFu : 0u;
-        lo |= b.w[i] & ml; hi |= b.w[i] & mh;
+    TAFL_UNROLL for (int i = 0; i < NL; ++i) {         // limb wi and its successor (selects, no dynamic indexing)
+        lo = ((uint32_t)i == wi) ? b.w[i] : lo;
+        hi = ((uint32_t)i == wi + 1) ? b.w[i] : hi;
     }
-    const uint64_t v = ((uint64_t)hi << 32) | lo;
-    return (uint32_t)(v >> off) & 31u;
+    // funnel shift of the limb pair (v_alignbit_b32 on gfx950)
+    const uint32_t v = off ? ((lo >> off) | (hi << ((32 - off) & 31))) : lo;
+    return v & 31u;
 }
 
 // position of the j-th (0-based) set bit of a 32-bit word, j < popcount(v)

@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--cpuct", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / reductions (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -78,8 +80,11 @@ def main():
             raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    tdist.init("nccl", rank, world)          # RCCL: only for the barrier and the max-reduce of the elapsed time
+    tdist.init(args.backend, rank, world)    # RCCL: only for the barrier and the max-reduce of the elapsed time
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     from alphazeroforhnefatafl_amd import abi
     from alphazeroforhnefatafl_amd.engine import KC_MCTS_BACKUP, KC_MCTS_ROLLOUT, KC_MCTS_TREE, BatchedGameLogic
@@ -115,11 +120,11 @@ def main():
     tree_ms, tree_n = logic.timing_get(KC_MCTS_TREE)
     bk_ms, bk_n = logic.timing_get(KC_MCTS_BACKUP)
 
-    elapsed = tdist.max_over_ranks(elapsed, world, device="cuda")
+    elapsed = tdist.max_over_ranks(elapsed, world, device=red_dev)
 
     total_sims = float(world) * G * args.sims * args.steps
     plies_per_step = float(stats.rollout_plies)
-    total_plies = tdist.sum_over_ranks(plies_per_step, world, device="cuda") * args.steps
+    total_plies = tdist.sum_over_ranks(plies_per_step, world, device=red_dev) * args.steps
     if rank == 0:
         # playouts actually executed by k_mcts_rollout in the last step: consumed ones + mispredicted speculative ones
         executed = int(stats.rollouts - stats.spec_hits + stats.spec_issued)
