@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--cpuct", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--board", default="copenhagen11", choices=["copenhagen11", "copenhagen13", "brandubh7"],
+                    help="copenhagen11 = the headline workload (BASELINE configs[2]); copenhagen13 = configs[4] (U256 multi-word path)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the barrier / reductions (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -90,9 +92,12 @@ def main():
     from alphazeroforhnefatafl_amd.engine import KC_MCTS_BACKUP, KC_MCTS_ROLLOUT, KC_MCTS_TREE, BatchedGameLogic
 
     stream = torch.cuda.Stream()
-    logic = BatchedGameLogic(abi.rules.COPENHAGEN, SIDE, WORD_BITS, device=local_rank, stream=stream.cuda_stream)
+    rules_, fen_, side_, wb_ = {"copenhagen11": (abi.rules.COPENHAGEN, abi.boards.COPENHAGEN, 11, 128),
+                                "copenhagen13": (abi.rules.COPENHAGEN, abi.boards.COPENHAGEN13, 13, 256),
+                                "brandubh7": (abi.rules.BRANDUBH, abi.boards.BRANDUBH, 7, 64)}[args.board]
+    logic = BatchedGameLogic(rules_, side_, wb_, device=local_rank, stream=stream.cuda_stream)
     G = args.games
-    batch = logic.new_batch(G, abi.boards.COPENHAGEN)        # synthetic data: every game at the start position
+    batch = logic.new_batch(G, fen_)                          # synthetic data: every game at the start position
     batch.mcts_reserve(args.sims)
     base = tdist.shard_base(rank, G)                          # contiguous global game-id shards, no collective on the data path
 
@@ -129,14 +134,15 @@ def main():
         # playouts actually executed by k_mcts_rollout in the last step: consumed ones + mispredicted speculative ones
         executed = int(stats.rollouts - stats.spec_hits + stats.spec_issued)
         roll_s_per_step = roll_ms * 1e-3 / args.steps
-        alg_bytes_per_step = ROLLOUT_BYTES_PER_GAME * executed
+        sg_bytes = {7: 48, 11: 64, 13: 96}[side_]
+        alg_bytes_per_step = (sg_bytes + 4) * executed
         achieved = alg_bytes_per_step / roll_s_per_step / 1e9 if roll_s_per_step > 0 else 0.0
         d_bar = stats.tree_depth_sum / max(stats.sims, 1)
         c_bar = stats.children_scanned / max(stats.tree_depth_sum, 1)
-        bytes_per_sim = d_bar * (64 + 16 * c_bar) + 32 + 2 * STATE_BYTES + 4     # SURVEY.md §8d formula
+        bytes_per_sim = d_bar * (64 + 16 * c_bar) + 32 + 2 * sg_bytes + 4        # SURVEY.md §8d formula
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_k_mcts_rollout.json")
-        if os.path.exists(tpath) and G == GAMES_PER_GPU:
+        if os.path.exists(tpath) and G == GAMES_PER_GPU and args.board == "copenhagen11" and args.sims == 64:
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_step")        # rocprofv3 PMC passes of this same command (profiles/)
         out = {
@@ -144,8 +150,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: full MCTS (select/expand/random-rollout/backup), "
-                                   "65536 concurrent 11x11 Copenhagen games per GPU from the start position",
+            "config": {"workload": ("BASELINE configs[2]" if args.board == "copenhagen11" and G == GAMES_PER_GPU else "variant") +
+                                   f": full MCTS (select/expand/random-rollout/backup), {G} concurrent {side_}x{side_} "
+                                   f"{args.board} games per GPU from the start position",
                        "games_per_gpu": G, "sims_per_root": args.sims, "max_rollout_plies": args.max_plies,
                        "c_puct": args.cpuct, "seed": args.seed, "sharding": f"game-id ranges x{world}, no collectives"},
             "env_steps_per_sec": total_plies / elapsed,
@@ -165,7 +172,7 @@ def main():
                          "note": "register-resident playout: 68 algorithmic bytes per playout; the binding limit is integer VALU issue "
                                  "(79 % of the measured 1-instruction-per-4-cycles-per-SIMD peak, profiles/r01_v6_pipeline), see DESIGN.md section 6"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.board == "copenhagen11":
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpuct, args.seed, args.max_plies)
         print(json.dumps(out), flush=True)
     if world > 1:
