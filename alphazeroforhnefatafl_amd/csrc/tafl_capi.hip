@@ -314,8 +314,9 @@ struct tafl_batch {
     MctsMem mem; bool has_mem; uint32_t reserved_sims;
     DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, rvalue, fault, stats, children, children_n, visits;
     DevBuf best_plays, best_visits, enc, policy;
+    DevBuf spec_cool;
     DevBuf sim_next, spec_state, spec_value, spec_kind, spec_reason, spec_plies, spec_parent, spec_o0, spec_first, spec_n;
-    uint32_t spec_k;
+    uint32_t spec_k, spec_cooldown;
     tafl_mcts_stats last_stats; bool ran;
 };
 
@@ -454,6 +455,7 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     if (!b) return fail(TAFL_ERR_OOM, "out of host memory");
     b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr;
     { const char* e = getenv("TAFL_SPEC_K"); int k = e ? atoi(e) : 2; b->spec_k = (uint32_t)(k < 1 ? 1 : (k > 8 ? 8 : k)); }
+    { const char* e = getenv("TAFL_SPEC_COOLDOWN"); int v = e ? atoi(e) : 0; b->spec_cooldown = (uint32_t)(v < 0 ? 0 : (v > 200 ? 200 : v)); }
     memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats);
     const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
     if (hipMalloc((void**)&b->soa, bytes) != hipSuccess) { delete b; return fail(TAFL_ERR_OOM, "hipMalloc(batch states) failed"); }
@@ -470,7 +472,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n, &b->best_plays, &b->best_visits, &b->enc, &b->policy};
+                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->spec_cool};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return TAFL_OK;
@@ -671,14 +673,14 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     const size_t k = b->spec_k;
     NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * quads_of(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n);
     NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_parent, n * 4); NEED(b->spec_o0, n * 4); NEED(b->spec_first, n * 4);
-    NEED(b->spec_n, n);
+    NEED(b->spec_n, n); NEED(b->spec_cool, n);
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
     b->mem.kind = (uint8_t*)b->kind.p; b->mem.rvalue = (int8_t*)b->rvalue.p; b->mem.fault = (uint8_t*)b->fault.p;
     b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p;
     b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
     b->mem.spec_parent = (uint32_t*)b->spec_parent.p; b->mem.spec_o0 = (int32_t*)b->spec_o0.p; b->mem.spec_first = (uint32_t*)b->spec_first.p;
-    b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_k = b->spec_k;
+    b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_cool = (uint8_t*)b->spec_cool.p; b->mem.spec_k = b->spec_k; b->mem.spec_cooldown = b->spec_cooldown;
     b->mem.G = b->n; b->mem.node_cap = (uint32_t)node_cap; b->mem.edge_cap = (uint32_t)edge_cap;
     b->has_mem = true; b->reserved_sims = max_sims;
     return TAFL_OK;
@@ -699,18 +701,57 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_init<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, M));
     // Every tree launch completes at least one simulation per unfinished game, so n_sims rounds always suffice; with
     // spec_k playout slots per game a round usually completes ~spec_k, and launches whose waves are all done return at once.
+    // Speculation pays only while enough speculative playouts are consumed: a round with k slots costs C_k and completes
+    // 1 + h simulations per game (h = hit fraction), a round without costs C_1 and completes 1; so it is kept on while
+    // 1 + h > C_k / C_1.  h and the two round times are sampled every 8 rounds (one sync each); when off, speculation is
+    // re-probed for 8 rounds every 64.  Results do not depend on any of this (tafl_ops.hpp mcts_tree_step).
     const uint32_t bps = grid_of(n);
+    const uint32_t full_k = b->spec_k;
+    uint32_t k_now = full_k, rounds_in_mode = 0;
+    unsigned long long last_issued = 0, last_hits = 0;
+    double last_hit = 1.0;
+    double round_ms[2] = {-1.0, -1.0};                       // [0] without speculation, [1] with
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (full_k > 1) { HIPCHK(hipEventCreate(&ev_a)); HIPCHK(hipEventCreate(&ev_b)); }
     for (uint32_t i = 0; i < p->n_sims; ++i) {
+        M.spec_k = k_now;
+        const bool sample = full_k > 1 && ((k_now > 1 && (rounds_in_mode + 1) % 8 == 0) ||
+                                           (k_now == 1 && (rounds_in_mode + 1 >= 64 || (round_ms[0] < 0 && rounds_in_mode + 1 == 4))));
+        if (sample) HIPCHK(hipEventRecord(ev_a, c->stream));
         {
             SpanGuard sg(c, KC_MCTS_TREE);
             DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, st));
         }
         {
             SpanGuard sg(c, KC_MCTS_ROLLOUT);
-            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(bps * b->spec_k), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->seed,
+            // slots of the previous mode may still be pending in the first round after a switch: keep the grid at full_k then
+            const uint32_t grid_k = (rounds_in_mode == 0) ? full_k : k_now;
+            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(bps * grid_k), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->seed,
                                                   game_id_base, p->sim_offset, p->max_rollout_plies, bps, st));
         }
+        ++rounds_in_mode;
+        if (sample) {
+            unsigned long long h[ST_COUNT];
+            HIPCHK(hipEventRecord(ev_b, c->stream));
+            HIPCHK(hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev_a, ev_b) == hipSuccess) round_ms[k_now > 1 ? 1 : 0] = ms;
+            if (h[ST_SIMS] >= (unsigned long long)n * p->n_sims) break;            // every game has finished
+            if (k_now > 1) {
+                const unsigned long long di = h[ST_SPEC_ISSUED] - last_issued, dh = h[ST_SPEC_HITS] - last_hits;
+                last_hit = di > 0 ? (double)dh / (double)di : 1.0;
+                const double ratio = (round_ms[0] > 0 && round_ms[1] > 0) ? round_ms[1] / round_ms[0] : 1.7;   // 1.7: measured, 11x11
+                if (1.0 + last_hit * (double)(full_k - 1) < ratio * 1.02) { k_now = 1; rounds_in_mode = 0; }
+            } else if (rounds_in_mode >= 64) { k_now = full_k; rounds_in_mode = 0; }      // periodic re-probe
+            else if (round_ms[1] > 0 && 1.0 + last_hit * (double)(full_k - 1) >= round_ms[1] / round_ms[0] * 1.02) {
+                k_now = full_k; rounds_in_mode = 0;      // first timing of a plain round says the default ratio was too pessimistic
+            }
+            last_issued = h[ST_SPEC_ISSUED]; last_hits = h[ST_SPEC_HITS];
+        }
     }
+    if (ev_a) { (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b); }
+    M.spec_k = full_k;
     {
         SpanGuard sg(c, KC_MCTS_BACKUP);
         DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, st));

@@ -89,7 +89,9 @@ struct MctsMem {
     int32_t* spec_o0;            // [G] ... -1: slot 0 is the (unexpanded) root itself
     uint32_t* spec_first;        // [G] simulation index of slot 0
     uint8_t* spec_n;             // [G] slots issued
-    uint32_t G, node_cap, edge_cap, spec_k;
+    uint8_t* spec_cool;          // [G] speculation is skipped while > 0 (set after a misprediction: phases of the search in which a
+                                 //     visited child beats the unvisited ones make the prediction fail repeatedly)
+    uint32_t G, node_cap, edge_cap, spec_k, spec_cooldown;
 };
 
 struct LaneStats {
@@ -229,7 +231,7 @@ struct Ops {
         M.hdr[g] = h;
         IO::store_rec(M.node_state + (size_t)g * IO::QUADS, root);
         M.node_top[g] = 1; M.edge_top[g] = 0; M.leaf[g] = 0; M.kind[g] = 0; M.rvalue[g] = 0; M.fault[g] = 0;
-        M.sim_next[g] = 0; M.spec_n[g] = 0; M.spec_parent[g] = 0; M.spec_o0[g] = 0; M.spec_first[g] = 0;
+        M.sim_next[g] = 0; M.spec_cool[g] = 0; M.spec_n[g] = 0; M.spec_parent[g] = 0; M.spec_o0[g] = 0; M.spec_first[g] = 0;
         for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;
     }
 
@@ -363,7 +365,12 @@ struct Ops {
             M.spec_kind[g] = 1;
             uint32_t cnt = 1;
             const NodeHdr ph = M.hdr[(size_t)P * M.G + g];
-            if (M.spec_k > 1 && sim + 1 < n_sims) {
+            // adaptive gate: a misprediction (speculative slots left unconsumed) pauses speculation for spec_cooldown issues
+            uint32_t cool = M.spec_cool[g];
+            if (had > 1 && sim < first + had) cool = M.spec_cooldown;
+            const bool speculate = cool == 0;
+            M.spec_cool[g] = (uint8_t)(cool > 0 ? cool - 1 : 0);
+            if (speculate && M.spec_k > 1 && sim + 1 < n_sims) {
                 S pst; IO::load_rec(M.node_state + ((size_t)P * M.G + g) * IO::QUADS, pst);
                 Move cur; cur.from = ph.cur_from; cur.to = 0; cur.dir = ph.cur_dir; cur.dist = ph.cur_dist;
                 const uint32_t pside = pst.flags & TAFL_F_SIDE;

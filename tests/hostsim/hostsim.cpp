@@ -11,6 +11,7 @@
 
 using namespace tafl;
 
+static uint32_t g_spec_cooldown = 0;   // see MctsMem::spec_cool
 static uint32_t g_spec_k = 2;          // playout slots per game in the MCTS pipeline (1 = no speculation)
 static bool g_force_generic = false;   // differential tests: generic Engine::rollout vs the fast playout engine
 
@@ -66,18 +67,18 @@ struct Host {
                     tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) {
         K C; if (consts(r, n, C)) return -1;
         using IO = StateIO<NL>;
-        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k;
+        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k; M.spec_cooldown = g_spec_cooldown;
         std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS), sst((size_t)M.spec_k * G * IO::QUADS);
         std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
         std::vector<Edge> edges((size_t)M.edge_cap * G);
         std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sparent(G), sfirst(G), splies((size_t)M.spec_k * G);
         std::vector<int32_t> so0(G);
-        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G);
+        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), scool(G);
         std::vector<int8_t> rv(G), sval((size_t)M.spec_k * G);
         M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
         M.leaf = leaf.data(); M.kind = kind.data(); M.rvalue = rv.data(); M.fault = fault.data();
         M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data();
-        M.spec_plies = splies.data(); M.spec_parent = sparent.data(); M.spec_o0 = so0.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data();
+        M.spec_plies = splies.data(); M.spec_parent = sparent.data(); M.spec_o0 = so0.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_cool = scool.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; state_from_abi<NL>(st[g], s); O::mcts_init_game(M, g, s, C); }
         auto tree = [&]() {
@@ -117,6 +118,7 @@ struct Host {
 extern "C" {
 void hs_force_generic(int on) { g_force_generic = on != 0; }
 void hs_set_spec_k(uint32_t k) { g_spec_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
+void hs_set_spec_cooldown(uint32_t c) { g_spec_cooldown = c > 200 ? 200 : c; }
 int hs_movegen(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint32_t* counts, uint32_t* masks, uint32_t mw) { DISPATCH(movegen(r, n, st, cnt, counts, masks, mw)) }
 int hs_validate(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_play* plays, uint8_t* codes) { DISPATCH(validate(r, n, st, cnt, plays, codes)) }
 int hs_step(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const tafl_play* plays, tafl_effects* eff) { DISPATCH(step(r, n, st, cnt, plays, eff)) }

@@ -32,6 +32,8 @@ def lib():
         sig("hs_rollout", P(TaflState), u32, u64, u32, u32, u64, P(TaflRolloutResult))
         sig("hs_random_advance", P(TaflState), u32, u64, P(u32), u64)
         sig("hs_mcts", P(TaflState), u32, P(TaflMctsParams), u64, P(TaflRootChild), u32, P(u32), P(TaflMctsStats))
+        L.hs_set_spec_cooldown.restype = None
+        L.hs_set_spec_cooldown.argtypes = [C.c_uint32]
         L.hs_set_spec_k.restype = None
         L.hs_set_spec_k.argtypes = [C.c_uint32]
         L.hs_force_generic.restype = None
@@ -98,6 +100,7 @@ def force_generic(on: bool):
     lib().hs_force_generic(int(on))
 
 
-def set_spec_k(k: int):
-    """Playout slots per game of the MCTS pipeline in host-sim runs (1 = no speculation)."""
+def set_spec_k(k: int, cooldown: int = 0):
+    """Playout slots per game of the MCTS pipeline in host-sim runs (1 = no speculation) and the misprediction cooldown."""
     lib().hs_set_spec_k(k)
+    lib().hs_set_spec_cooldown(cooldown)

@@ -140,14 +140,14 @@ def test_mcts(name, sims, cpuct):
     assert list(ostats.reason_hist) == list(hstats.reason_hist)
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 8])
-def test_mcts_speculative_slots_do_not_change_results(k):
+@pytest.mark.parametrize("k,cooldown", [(1, 2), (2, 0), (2, 2), (3, 1), (4, 5), (8, 0)])
+def test_mcts_speculative_slots_do_not_change_results(k, cooldown):
     """The MCTS pipeline with k playout slots per game (k-1 speculative) must reproduce the sequential search exactly:
     root statistics as float64 bit patterns and every counter, for start, mid-game and terminal-heavy positions."""
     import json
     import os
     from tests.hostsim import hostsim
-    hostsim.set_spec_k(k)
+    hostsim.set_spec_k(k, cooldown)
     try:
         gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mcts_golden.json")))
         for case in gold["cases"]:
@@ -183,4 +183,4 @@ def test_mcts_speculative_slots_do_not_change_results(k):
         assert list(ostats.reason_hist) == list(hstats.reason_hist)
         assert ostats.terminal_hits > 0
     finally:
-        hostsim.set_spec_k(2)
+        hostsim.set_spec_k(2, 0)
