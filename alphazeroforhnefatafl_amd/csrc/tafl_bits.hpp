@@ -20,6 +20,31 @@
 #define TAFL_UNROLL
 #endif
 
+// Section timers for profiling builds only (-DTAFL_PROF): per-section shader-clock totals, one lane per wave reporting.
+// Marks must sit on the path every game takes every ply.  Product builds compile them away.
+#if defined(TAFL_PROF) && defined(__HIP_DEVICE_COMPILE__)
+extern "C" __device__ unsigned long long tafl_prof_acc[4096 * 32];   // one row per workgroup: no contention
+#define TAFL_PROF_ADD_(k, v) do { const unsigned long long b_ = __ballot(1); \
+    if ((int)__lane_id() == __ffsll((long long)b_) - 1) atomicAdd(&tafl_prof_acc[(blockIdx.x & 4095u) * 32u + (k)], (unsigned long long)(v)); } while (0)
+#define TAFL_PROF_BEGIN(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); TAFL_PROF_ADD_(k, 0ull - t_); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TAFL_PROF_END(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); TAFL_PROF_ADD_(k, t_); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TAFL_PROF_SPLIT(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); TAFL_PROF_ADD_(k, t_); TAFL_PROF_ADD_((k) + 1, 0ull - t_); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TAFL_PROF_COUNT(k) TAFL_PROF_ADD_(k, 1ull)
+#else
+#define TAFL_PROF_BEGIN(k) do {} while (0)
+#define TAFL_PROF_END(k) do {} while (0)
+#define TAFL_PROF_SPLIT(k) do {} while (0)
+#define TAFL_PROF_COUNT(k) do {} while (0)
+#endif
+
+// event counters for host-side statistics builds only (-DTAFL_STAT, tests/hostsim experiments): how often a game takes a path
+#if defined(TAFL_STAT) && !defined(__HIP_DEVICE_COMPILE__)
+extern "C" unsigned long long tafl_stat_acc[32];
+#define TAFL_STAT_HIT(k) (++tafl_stat_acc[(k)])
+#else
+#define TAFL_STAT_HIT(k) ((void)0)
+#endif
+
 namespace tafl {
 
 // true if the predicate holds for ANY game of the wavefront (device) / for this game (host build): used to skip work that
@@ -143,18 +168,47 @@ template <int NL> TAFL_HD Bits<NL> below(uint32_t idx) {
     }
     return o;
 }
-// 5-bit window around idx: bit k of the result = bit (idx - 2 + k) of a (bits outside the word read as 0)
-template <int NL> TAFL_HD uint32_t window5(const Bits<NL>& a, uint32_t idx) {
-    const Bits<NL> b = shl<2>(a);                      // bit (idx-2) of a is bit idx of b: no negative positions
-    const uint32_t wi = idx >> 5, off = idx & 31;
-    uint32_t lo = 0, hi = 0;
-    TAFL_UNROLL for (int i = 0; i < NL; ++i) {         // limb wi and its successor (selects, no dynamic indexing)
-        lo = ((uint32_t)i == wi) ? b.w[i] : lo;
-        hi = ((uint32_t)i == wi + 1) ? b.w[i] : hi;
+// 64-bit field of `a` that starts BACK (<= 32) bits below idx: bit k of the result = bit (idx - BACK + k) of a; positions
+// outside the word read as 0.  With BACK = 2*W the tile idx sits at bit 2W and its row / column neighbours at distance 1
+// and 2 sit at the fixed bits 2W-2..2W+2 and 0, W, 3W, 4W (4W + 1 <= 61 for W <= 15).
+template <int BACK, int NL> TAFL_HD uint64_t field64(const Bits<NL>& a, uint32_t idx) {
+    static_assert(BACK >= 0 && BACK <= 32, "field64: BACK out of range");
+    if constexpr (NL == 2) {                           // the whole word is one 64-bit value: a shift either way
+        const uint64_t v = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32);
+        return idx >= (uint32_t)BACK ? (v >> ((idx - (uint32_t)BACK) & 63u)) : (v << (((uint32_t)BACK - idx) & 63u));
+    } else {
+        const uint32_t p = idx + 32u - (uint32_t)BACK; // position in [zero limb, a.w[0], a.w[1], ...]
+        const uint32_t wi = p >> 5, off = p & 31u;
+        uint32_t x0 = 0, x1 = 0, x2 = 0;
+        TAFL_UNROLL for (int i = 0; i < NL; ++i) {     // limbs wi-1, wi, wi+1 of a (selects, no dynamic indexing)
+            x0 = ((uint32_t)i + 1u == wi) ? a.w[i] : x0;
+            x1 = ((uint32_t)i == wi) ? a.w[i] : x1;
+            x2 = ((uint32_t)i == wi + 1u) ? a.w[i] : x2;
+        }
+        // funnel shifts (v_alignbit_b32 on gfx950)
+        const uint32_t lo = (uint32_t)((((uint64_t)x1 << 32) | x0) >> off);
+        const uint32_t hi = (uint32_t)((((uint64_t)x2 << 32) | x1) >> off);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
     }
-    // funnel shift of the limb pair (v_alignbit_b32 on gfx950)
-    const uint32_t v = off ? ((lo >> off) | (hi << ((32 - off) & 31))) : lo;
-    return v & 31u;
+}
+// inverse of field64: bit k of f goes to bit (idx - BACK + k); bits that fall outside the word are dropped
+template <int BACK, int NL> TAFL_HD Bits<NL> deposit64(uint64_t f, uint32_t idx) {
+    static_assert(BACK >= 0 && BACK <= 32, "deposit64: BACK out of range");
+    Bits<NL> o;
+    if constexpr (NL == 2) {
+        const uint64_t v = idx >= (uint32_t)BACK ? (f << ((idx - (uint32_t)BACK) & 63u)) : (f >> (((uint32_t)BACK - idx) & 63u));
+        o.w[0] = (uint32_t)v; o.w[1] = (uint32_t)(v >> 32);
+    } else {
+        const uint32_t p = idx + 32u - (uint32_t)BACK;
+        const uint32_t wi = p >> 5, off = p & 31u;
+        const uint32_t flo = (uint32_t)f, fhi = (uint32_t)(f >> 32);
+        const uint32_t y0 = flo << off;
+        const uint32_t y1 = (uint32_t)((f << off) >> 32);
+        const uint32_t y2 = (uint32_t)(((uint64_t)fhi << off) >> 32);
+        TAFL_UNROLL for (int i = 0; i < NL; ++i)
+            o.w[i] = ((uint32_t)i + 1u == wi) ? y0 : ((uint32_t)i == wi) ? y1 : ((uint32_t)i == wi + 1u) ? y2 : 0u;
+    }
+    return o;
 }
 
 // position of the j-th (0-based) set bit of a 32-bit word, j < popcount(v)

@@ -24,6 +24,17 @@ using namespace tafl;
 // kernels
 // --------------------------------------------------------------------------------------------------
 #define TAFL_BLOCK 64
+#ifdef TAFL_PROF
+// profiling builds only (never the product library): totals of the TAFL_PROF_* section timers
+extern "C" __device__ unsigned long long tafl_prof_acc[4096 * 32] = {};
+extern "C" int tafl_prof_read(unsigned long long* out, int reset) {
+    static unsigned long long h[4096 * 32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(tafl_prof_acc), sizeof h) != hipSuccess) return -1;
+    for (int k = 0; k < 32; ++k) { out[k] = 0; for (int w = 0; w < 4096; ++w) out[k] += h[w * 32 + k]; }
+    if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(tafl_prof_acc), h, sizeof h) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifndef TAFL_KATTR
 #define TAFL_KATTR
 #endif

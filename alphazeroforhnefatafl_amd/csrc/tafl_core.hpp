@@ -371,7 +371,9 @@ struct Engine {
         const uint32_t k = king_sq(st, C);
         if (k == TAFL_NO_SQ) return false;
         const B kt = bit_at<NL>(k);
+        TAFL_STAT_HIT(0);
         if (!any(kt & C.edge)) return false;
+        TAFL_STAT_HIT(1);
         const B occ = st.att | st.def;
         const B empty = andn(C.board, occ);
         const B attb = st.att & C.board;
@@ -381,14 +383,18 @@ struct Engine {
         // aborts, logic.rs:288-291), and the first ring is also the "king has space to move" test (logic.rs:590)
         const B d1 = dilate(kt, C);
         if (any(d1 & attb)) return false;
+        TAFL_STAT_HIT(2);
         if (!any(d1 & empty)) return false;
         const B f1 = kt | (d1 & empty);
         if (any(f1 & C.corners)) return false;
+        TAFL_STAT_HIT(3);
         const B d2 = dilate(f1, C);
         if (any(d2 & attb)) return false;
+        TAFL_STAT_HIT(4);
         const B inside = empty | (kt & st.def);
         B fill;
         if (!flood_from(f1 | (d2 & inside), inside, attb, false, true, C, fill)) return false;
+        TAFL_STAT_HIT(5);
         const B boundary = dilate(fill, C) & andn(st.def, fill);
         return secure(st, fill, boundary, CLS_DEF, true, false, C);
     }
@@ -437,107 +443,119 @@ struct Engine {
     }
 
     // ---- get_captures (logic.rs:604-699) on the post-move board, side_to_play still the mover ------------------
-    template <int DIR> static TAFL_HD B custodial_dir(const B& tbit, const B& victims, const B& hostile, bool edge_h, const K& C) {
-        constexpr int OPP = DIR ^ 1;
-        const B nb = step1<DIR>(tbit, C);
-        const B far_h = step1<OPP>(hostile, C) | gate(lastline<DIR>(C), edge_h);
-        return nb & victims & far_h;
-    }
-    // sw_hint: -1 = evaluate the shieldwall pre-filter here; 0 / 1 = the caller already did (fast playout engine)
-    static TAFL_HD B captures(const S& st, const Move& m, uint32_t mover, bool mover_is_king, const K& C, int sw_hint = -1) {
+    // Custodial captures, the king capture and the shieldwall pre-filter are evaluated on 64-bit fields around the destination
+    // (field64, tafl_bits.hpp): with the field starting BK = 2W+1 bits below `to`, the four neighbours sit at the fixed bits
+    // BK-1, BK+1, BK-W, BK+W, the tiles behind them at BK-2, BK+2, BK-2W, BK+2W, and every tile the king test or the
+    // shieldwall filter looks at lies within BK-2W-1 .. BK+2W+1 = 0 .. 4W+2 <= 62; validity (board limits, row wrap) comes
+    // from (row, col).  Straight-line on purpose: 64 games share an instruction stream, so a branch that 1 % of the games
+    // take is taken by half of the waves.
+    // cust_out: which directions captured custodially — bit0 V+ (row+1), bit1 V-, bit2 H+ (col+1), bit3 H-.
+    static TAFL_HD B captures(const S& st, const Move& m, uint32_t mover, bool mover_is_king, const K& C, uint32_t* cust_out = nullptr) {
+        constexpr int BK = 2 * W + 1;
+        static_assert(BK <= 32 && 4 * W + 2 < 64, "field layout needs W <= 15");
         B caps = bz<NL>();
-        const B tbit = bit_at<NL>(m.to);
-        const B occ = st.att | st.def;
-        const B empty = andn(C.board, occ);
-        const B kb = king_bit(st, C);
+        uint32_t cust = 0;
+        const uint32_t to = m.to, r = to / (uint32_t)W, c = to % (uint32_t)W, n = C.n;
+        const uint64_t fa = field64<BK>(st.att, to), fd = field64<BK>(st.def, to);
+        const uint64_t fm = mover ? fd : fa, ft = mover ? fa : fd;
+        const uint32_t kq = king_sq(st, C);
+        const uint32_t krel = kq - to + (uint32_t)BK;                    // field position of the king's tile (>= 64: outside / no king)
+        const uint64_t kf = krel < 64u ? ((1ull << krel) & fd) : 0ull;   // the king, if he stands inside the field
+        auto bit = [](uint64_t f, int pos) -> uint32_t { return (uint32_t)(f >> pos) & 1u; };
+        auto vbit = [](uint64_t f, uint32_t pos) -> uint32_t { return (uint32_t)(f >> (pos & 63u)) & 1u; };
         if (!mover_is_king || C.rules.king_attack == TAFL_KING_ARMED || C.rules.king_attack == TAFL_KING_HAMMER) {
-            // hostile-to-victim occupied tiles: mover-side pieces, an unarmed king excluded (tile_hostile :85-93)
-            B friends = (mover ? st.def : st.att) & C.board;
-            if (mover && !king_armed_as_anvil(C)) friends = andn(friends, kb);
-            // victim class = the other side's soldiers; constants picked with selects (a run-time array index into the
-            // constants would become a memory load inside the playout loop)
-            const B victims = mover ? (st.att & C.board) : andn(st.def & C.board, kb);   // enemy soldiers
-            const B hostile = friends | (empty & blend(mover != 0, C.hostile_special[CLS_ATT], C.hostile_special[CLS_DEF]));
+            // hostile-to-victim occupied tiles: mover-side pieces, an unarmed king excluded (tile_hostile :85-93);
+            // victim class = the other side's soldiers
+            const uint64_t friends = (mover && !king_armed_as_anvil(C)) ? (fm & ~kf) : fm;
+            const uint64_t victims = mover ? ft : (ft & ~kf);
+            const uint64_t hs = field64<BK>(blend(mover != 0, C.hostile_special[CLS_ATT], C.hostile_special[CLS_DEF]), to);
+            const uint64_t hostile = friends | (hs & ~(fa | fd));
             const uint32_t mm = mover ? 0xFFFFFFFFu : 0u;
-            const bool eh = ((C.edge_hostile[CLS_ATT] & mm) | (C.edge_hostile[CLS_DEF] & ~mm)) != 0;
-            B cs = custodial_dir<DIR_VP>(tbit, victims, hostile, eh, C) | custodial_dir<DIR_VM>(tbit, victims, hostile, eh, C)
-                 | custodial_dir<DIR_HP>(tbit, victims, hostile, eh, C) | custodial_dir<DIR_HM>(tbit, victims, hostile, eh, C);
+            const uint32_t eh = (((C.edge_hostile[CLS_ATT] & mm) | (C.edge_hostile[CLS_DEF] & ~mm)) != 0) ? 1u : 0u;
+            const uint32_t vp = (uint32_t)(r + 1 < n) & bit(victims, BK + W) & ((r + 2 < n) ? bit(hostile, BK + 2 * W) : eh);
+            const uint32_t vm = (uint32_t)(r >= 1) & bit(victims, BK - W) & ((r >= 2) ? bit(hostile, BK - 2 * W) : eh);
+            const uint32_t hp = (uint32_t)(c + 1 < n) & bit(victims, BK + 1) & ((c + 2 < n) ? bit(hostile, BK + 2) : eh);
+            const uint32_t hm = (uint32_t)(c >= 1) & bit(victims, BK - 1) & ((c >= 2) ? bit(hostile, BK - 2) : eh);
+            cust = vp | (vm << 1) | (hp << 2) | (hm << 3);
+            const uint64_t cf = ((uint64_t)vp << (BK + W)) | ((uint64_t)vm << (BK - W)) | ((uint64_t)hp << (BK + 1)) | ((uint64_t)hm << (BK - 1));
+            B cs = deposit64<BK, NL>(cf, to);
             // Linnaean capture (logic.rs:676-685, :859-879): only for victims whose far tile was not hostile
-            if (C.rules.linnaean_capture && mover == 0 && any(kb & C.throne)) {
-                const B hk = (st.att & C.board) | (empty & C.hostile_special[CLS_KING]);
-                if (popc(C.throne_nb & hk) == 3) {
-                    // victim n adjacent to `to` with far == throne: n is a throne neighbour in line with `to`
-                    B lin = (step1<DIR_VP>(tbit, C) & step1<DIR_VM>(C.throne, C)) | (step1<DIR_VM>(tbit, C) & step1<DIR_VP>(C.throne, C))
-                          | (step1<DIR_HP>(tbit, C) & step1<DIR_HM>(C.throne, C)) | (step1<DIR_HM>(tbit, C) & step1<DIR_HP>(C.throne, C));
-                    cs |= lin & victims;
+            if (C.rules.linnaean_capture && mover == 0) {
+                const B kb = king_bit(st, C);
+                if (any(kb & C.throne)) {
+                    const B empty = andn(C.board, st.att | st.def);
+                    const B hk = (st.att & C.board) | (empty & C.hostile_special[CLS_KING]);
+                    if (popc(C.throne_nb & hk) == 3) {
+                        // victim n adjacent to `to` with far == throne: n is a throne neighbour in line with `to`
+                        const B tbit = bit_at<NL>(to);
+                        const B lin = (step1<DIR_VP>(tbit, C) & step1<DIR_VM>(C.throne, C)) | (step1<DIR_VM>(tbit, C) & step1<DIR_VP>(C.throne, C))
+                                    | (step1<DIR_HP>(tbit, C) & step1<DIR_HM>(C.throne, C)) | (step1<DIR_HM>(tbit, C) & step1<DIR_HP>(C.throne, C));
+                        cs |= lin & andn(st.def & C.board, kb);
+                    }
                 }
             }
             caps |= cs;
-            // enemy king next to the destination (only an attacker can face it)
+            TAFL_PROF_SPLIT(1);
+            // enemy king next to the destination (only an attacker can face it), logic.rs:612-675
 #ifndef TAFL_ABLATE_KINGCAP
-            const uint32_t kq = king_sq(st, C);
-            const uint32_t kd = m.to > kq ? m.to - kq : kq - m.to;
-            const bool king_adjacent = mover == 0 && kq != TAFL_NO_SQ && any(kb)
-                                       && (kd == (uint32_t)W || (kd == 1u && m.to / (uint32_t)W == kq / (uint32_t)W));
-            if (king_adjacent) {
-                const uint32_t k = kq;
-                const B hk = (st.att & C.board) | (empty & C.hostile_special[CLS_KING]);   // tile_hostile(·, king)
-                const bool ehk = C.edge_hostile[CLS_KING] != 0;
-                const bool beside = any(kb & C.throne_nb);
+            const uint32_t kr = TAFL_F_KROW(st.flags), kc = TAFL_F_KCOL(st.flags);
+            const uint32_t kd = to > kq ? to - kq : kq - to;
+            const bool king_adjacent = mover == 0 && kf != 0ull && (kd == (uint32_t)W || (kd == 1u && r == kr));
+            if (king_adjacent) TAFL_STAT_HIT(9);
+            if (wave_any(king_adjacent)) {
+                // tile_hostile(., king) on the field; the king's other three neighbours: `far` opposite the attacker, and the
+                // two perpendicular ones
+                const uint64_t hk = fa | (field64<BK>(C.hostile_special[CLS_KING], to) & ~(fa | fd));
+                const uint32_t ehk = C.edge_hostile[CLS_KING] != 0 ? 1u : 0u;
+                const bool same_row = kr == r;
+                const uint32_t pstep = same_row ? (uint32_t)W : 1u;
+                const uint32_t far_pos = 2u * krel - (uint32_t)BK, p1_pos = krel + pstep, p2_pos = krel - pstep;
+                const uint32_t fr = 2u * kr - r, fc = 2u * kc - c;                               // wraps to >= n when off the board
+                const bool far_on = fr < n && fc < n;
+                const bool p1_on = same_row ? (kr + 1 < n) : (kc + 1 < n), p2_on = same_row ? (kr >= 1) : (kc >= 1);
+                const uint32_t far_h = vbit(hk, far_pos), p1_h = vbit(hk, p1_pos), p2_h = vbit(hk, p2_pos);
+                const uint32_t far_sq = 2u * kq - to, p1_sq = kq + pstep, p2_sq = kq - pstep;
+                const bool beside = test(C.throne_nb, kq & 0xFFu);
                 bool captured = false;
-                // (i) strong-by-throne king beside his throne, every neighbour hostile or the throne (logic.rs:621-632)
-                if (beside && C.rules.king_strength == TAFL_KING_STRONG_BY_THRONE
+                // (i) strong-by-throne king beside his throne: every on-board neighbour hostile or the throne (logic.rs:621-632)
+                if (C.rules.king_strength == TAFL_KING_STRONG_BY_THRONE
                     && (C.rules.throne_movement == TAFL_THRONE_NOENTRY || C.rules.throne_movement == TAFL_THRONE_KINGENTRY)) {
-                    const B nbk = dilate(kb, C);
-                    if (!any(andn(andn(nbk, C.throne), hk))) captured = true;
+                    const bool ok_far = !far_on || far_h || far_sq == C.throne_sq;
+                    const bool ok_p1 = !p1_on || p1_h || p1_sq == C.throne_sq;
+                    const bool ok_p2 = !p2_on || p2_h || p2_sq == C.throne_sq;
+                    captured = beside && ok_far && ok_p1 && ok_p2;
                 }
-                if (!captured) {
-                    // (ii) far tile hostile (logic.rs:634-675)
-                    const int kr = (int)(k / (uint32_t)W), kc = (int)(k % (uint32_t)W);
-                    const int tr = (int)(m.to / (uint32_t)W), tc = (int)(m.to % (uint32_t)W);
-                    const int fr = tr + (kr - tr) * 2, fc = tc + (kc - tc) * 2;
-                    auto host = [&](int r, int c) -> bool {
-                        if (r < 0 || c < 0 || r >= (int)C.n || c >= (int)C.n) return ehk;
-                        return test(hk, (uint32_t)r * (uint32_t)W + (uint32_t)c);
-                    };
-                    if (host(fr, fc)) {
-                        bool strong;
-                        switch (C.rules.king_strength) {
-                            case TAFL_KING_STRONG: strong = true; break;
-                            case TAFL_KING_WEAK: strong = false; break;
-                            default: strong = beside || any(kb & C.throne); break;
-                        }
-                        if (strong) {
-                            const bool perp = (tr == kr) ? (host(kr + 1, kc) && host(kr - 1, kc)) : (host(kr, kc + 1) && host(kr, kc - 1));
-                            captured = perp;
-                        } else captured = true;
-                    }
+                // (ii) far tile hostile, and for a strong king both perpendicular tiles too (logic.rs:634-675)
+                const bool host_far = far_on ? far_h != 0 : ehk != 0;
+                const bool host_p1 = p1_on ? p1_h != 0 : ehk != 0, host_p2 = p2_on ? p2_h != 0 : ehk != 0;
+                bool strong;
+                switch (C.rules.king_strength) {
+                    case TAFL_KING_STRONG: strong = true; break;
+                    case TAFL_KING_WEAK: strong = false; break;
+                    default: strong = beside || kq == C.throne_sq; break;
                 }
-                if (captured) caps |= kb;
+                captured = captured || (host_far && (!strong || (host_p1 && host_p2)));
+                caps |= gate(bit_at<NL>(kq & 0xFFu), king_adjacent && captured);
             }
 #endif
         }
+        TAFL_PROF_SPLIT(2);
 #ifndef TAFL_ABLATE_SW
         if (C.rules.has_shieldwall) {
-            // A wall captures only if >= 2 enemy pieces stand in a row next to `to` along its edge (logic.rs:507,527,556):
-            // test those two tiles before paying for the edge walk (with 64 games per wave the walk would otherwise run on
-            // every ply: 23 % of plays end on an edge, 0.3 % pass this test).
-            bool cand;
-            if (sw_hint >= 0) cand = sw_hint != 0;
-            else {
-                const B theirs = blend(mover != 0, st.att, st.def);
-                const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W, n = C.n;
-                // straight-line on purpose (no short-circuit): with one wave per SIMD every branch costs tens of cycles
-                const uint32_t hp = (uint32_t)test(theirs, m.to + 1) & (uint32_t)test(theirs, m.to + 2) & (uint32_t)(c + 2 < n);
-                const uint32_t hm = (uint32_t)test(theirs, m.to - 1) & (uint32_t)test(theirs, m.to - 2) & (uint32_t)(c >= 2);
-                const uint32_t vp = (uint32_t)test(theirs, m.to + (uint32_t)W) & (uint32_t)test(theirs, m.to + 2u * (uint32_t)W) & (uint32_t)(r + 2 < n);
-                const uint32_t vm = (uint32_t)test(theirs, m.to - (uint32_t)W) & (uint32_t)test(theirs, m.to - 2u * (uint32_t)W) & (uint32_t)(r >= 2);
-                const uint32_t row_edge = (uint32_t)(r == 0) | (uint32_t)(r == n - 1), col_edge = (uint32_t)(c == 0) | (uint32_t)(c == n - 1);
-                cand = ((row_edge & (hp | hm)) | (col_edge & (vp | vm))) != 0;
-            }
-            if (cand) caps |= shieldwall(st, m.to, mover, C);
+            // A wall captures only if >= 2 enemy pieces stand in a row next to `to` along its edge, each pinned by a piece of
+            // the mover on its inner side (logic.rs:507-530,556): test those four tiles before paying for the edge walk.
+            const uint64_t pe_row = ft & ((r == 0) ? (fm >> W) : (fm << W));      // enemy with a mover piece one row inwards
+            const uint64_t pe_col = ft & ((c == 0) ? (fm >> 1) : (fm << 1));      //                   ... one column inwards
+            const uint32_t hp = bit(pe_row, BK + 1) & bit(pe_row, BK + 2) & (uint32_t)(c + 2 < n);
+            const uint32_t hm = bit(pe_row, BK - 1) & bit(pe_row, BK - 2) & (uint32_t)(c >= 2);
+            const uint32_t vp = bit(pe_col, BK + W) & bit(pe_col, BK + 2 * W) & (uint32_t)(r + 2 < n);
+            const uint32_t vm = bit(pe_col, BK - W) & bit(pe_col, BK - 2 * W) & (uint32_t)(r >= 2);
+            const uint32_t row_edge = (uint32_t)(r == 0) | (uint32_t)(r == n - 1), col_edge = (uint32_t)(c == 0) | (uint32_t)(c == n - 1);
+            if (((row_edge & (hp | hm)) | (col_edge & (vp | vm))) != 0) { TAFL_STAT_HIT(8); caps |= shieldwall(st, to, mover, C); }
         }
 #endif
+        TAFL_PROF_SPLIT(3);
+        if (cust_out) *cust_out = cust;
         return caps;
     }
 
@@ -546,15 +564,16 @@ struct Engine {
         const uint32_t fr = m.from / (uint32_t)W, fc = m.from % (uint32_t)W;
         const bool horiz = m.dir >= 2; const int disp = (m.dir & 1) ? -(int)m.dist : (int)m.dist;
         const uint32_t rec = TAFL_REP_PACK(mover, fr, fc, horiz, disp, captured);
-        uint32_t ar = st.reps & 0xFFFFu, dr = st.reps >> 16;
-        if (!captured && rec == st.rep[0]) {
-            const uint32_t midbit = mover ? TAFL_F_DMID : TAFL_F_AMID;
-            const bool is_rep = !(st.flags & midbit);
-            st.flags ^= midbit;
-            if (is_rep) { if (mover) dr = dr < 0xFFFFu ? dr + 1 : dr; else ar = ar < 0xFFFFu ? ar + 1 : ar; }
-        } else {
-            if (mover) { dr = 0; st.flags &= ~TAFL_F_DMID; } else { ar = 0; st.flags &= ~TAFL_F_AMID; }
-        }
+        // branch-free: `hit` = this play repeats the one four plies back; every second hit counts (the mid-pair flag toggles);
+        // a miss clears the mover's counter and flag
+        const uint32_t sh = mover ? 16u : 0u;
+        const uint32_t midbit = mover ? TAFL_F_DMID : TAFL_F_AMID;
+        const bool hit = !captured && rec == st.rep[0];
+        const bool is_rep = hit && !(st.flags & midbit);
+        const uint32_t cur = (st.reps >> sh) & 0xFFFFu;
+        const uint32_t nxt = hit ? (cur + ((is_rep && cur < 0xFFFFu) ? 1u : 0u)) : 0u;
+        st.flags = hit ? (st.flags ^ midbit) : (st.flags & ~midbit);
+        const uint32_t ar = mover ? (st.reps & 0xFFFFu) : nxt, dr = mover ? nxt : (st.reps >> 16);
         st.reps = ar | (dr << 16);
         st.rep[0] = st.rep[1]; st.rep[1] = st.rep[2]; st.rep[2] = st.rep[3]; st.rep[3] = rec;
     }
@@ -564,24 +583,24 @@ struct Engine {
     //   apply_pre      move the piece, captures, removal, repetition tracker             (logic.rs:787-799)
     //   outcome_early  every outcome test that precedes the no-plays test              (logic.rs:709-758)
     //   apply_finish   no-plays test from the opponent's move count, turn/side/status  (logic.rs:760-816)
-    struct ApplyCtx { uint32_t mover; bool mover_is_king, king_captured; B tbit, caps; uint32_t ncap; };
+    struct ApplyCtx { uint32_t mover; bool mover_is_king, king_captured; B tbit, caps; uint32_t ncap, cust; };
     struct Outcome { bool over; uint32_t status, reason, winner; };
 
-    static TAFL_HD void apply_pre(S& st, const Move& m, const K& C, ApplyCtx& ax, int sw_hint = -1) {
+    // `m` must be a valid play of the side to move (destination empty).
+    static TAFL_HD void apply_pre(S& st, const Move& m, const K& C, ApplyCtx& ax) {
         const uint32_t mover = st.flags & TAFL_F_SIDE;
         const B fbit = bit_at<NL>(m.from), tbit = bit_at<NL>(m.to);
         const bool mover_is_king = mover && m.from == king_sq(st, C);
-        // board.move_piece (board/state.rs:218-223)
+        // board.move_piece (board/state.rs:218-223): clear `from`, set `to` on the mover's side — branch-free
         {
-            // mover side: clear `from`, set `to`; other side: clear `to` (set_piece, board/state.rs:149-165) — branch-free
-            const B dm = gate(fbit | tbit, mover != 0), am = gate(fbit | tbit, mover == 0);
-            st.def = andn(st.def, dm | tbit) | gate(tbit, mover != 0);
-            st.att = andn(st.att, am | tbit) | gate(tbit, mover == 0);
+            const B mv = fbit | tbit;
+            st.def = st.def ^ gate(mv, mover != 0);
+            st.att = st.att ^ gate(mv, mover == 0);
             const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W;
             const uint32_t kf = (st.flags & ~0x00FF0000u) | (r << 16) | (c << 20);
             st.flags = mover_is_king ? kf : st.flags;
         }
-        const B caps = captures(st, m, mover, mover_is_king, C, sw_hint);
+        const B caps = captures(st, m, mover, mover_is_king, C, &ax.cust);
         ax.king_captured = mover == 0 && king_sq(st, C) != TAFL_NO_SQ && test(caps, king_sq(st, C));
         st.att = andn(st.att, caps); st.def = andn(st.def, caps);
         ax.ncap = popc(caps); ax.caps = caps; ax.mover = mover; ax.mover_is_king = mover_is_king; ax.tbit = tbit;
@@ -600,6 +619,8 @@ struct Engine {
             if (ax.king_captured) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_KING_CAPTURED; o.winner = 0; o.over = true; }
 #ifndef TAFL_ABLATE_FLOOD
             else if (C.rules.enclosure_win != TAFL_ENCL_NONE && !skip_enclosure) {
+                TAFL_PROF_BEGIN(8);
+                TAFL_STAT_HIT(10);
                 B fill;
                 const B inside = andn(C.board, st.att);
                 if (flood(king_sq(st, C), inside, bz<NL>(), C.rules.enclosure_win == TAFL_ENCL_WITHOUT_EDGE_ACCESS, true, C, fill)) {
@@ -610,6 +631,7 @@ struct Engine {
                         }
                     }
                 }
+                TAFL_PROF_END(8);
             }
 #endif
         } else if (!o.over) {
@@ -617,8 +639,11 @@ struct Engine {
                 o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_KING_ESCAPED; o.winner = 1; o.over = true;
             }
 #ifndef TAFL_ABLATE_FORT
-            else if (C.rules.exit_fort && exit_fort(st, C)) {
-                o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_EXIT_FORT; o.winner = 1; o.over = true;
+            else if (C.rules.exit_fort) {
+                TAFL_PROF_BEGIN(9);
+                const bool fort = exit_fort(st, C);
+                TAFL_PROF_END(9);
+                if (fort) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_EXIT_FORT; o.winner = 1; o.over = true; }
             }
 #endif
         }

@@ -172,37 +172,44 @@ struct Fast {
         uint32_t ply = 0; bool stuck = false;
         while (ply < max_plies && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
             if (g.total == 0) { stuck = true; break; }
+            TAFL_PROF_COUNT(31); TAFL_STAT_HIT(31);
+            TAFL_PROF_BEGIN(10); TAFL_PROF_SPLIT(10); TAFL_PROF_END(11);      // two empty sections: the cost of a mark
+            TAFL_PROF_BEGIN(0);
             const uint32_t idx = E::mulhi(E::ply_rand(sk, ply), g.total);
             const Move m = pick(st, attT, defT, g, idx, C);
-            // shieldwall pre-filter (two enemy pieces in a row next to `to` along its edge, logic.rs:507,527,556) from 5-bit
-            // windows: row edges are lines of the N layout, column edges are lines of the T layout
-            int sw_hint = 0;
-            if (C.rules.has_shieldwall) {
-                const bool mv = (st.flags & TAFL_F_SIDE) != 0;
-                const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W, n = C.n;
-                const uint32_t wn = window5(blend(mv, st.att, st.def), m.to), wt = window5(blend(mv, attT, defT), n_to_t(m.to));
-                const uint32_t row_edge = (uint32_t)(r == 0) | (uint32_t)(r == n - 1), col_edge = (uint32_t)(c == 0) | (uint32_t)(c == n - 1);
-                const uint32_t h = ((uint32_t)((wn & 0x18u) == 0x18u) & (uint32_t)(c + 2 < n)) | ((uint32_t)((wn & 3u) == 3u) & (uint32_t)(c >= 2));
-                const uint32_t v = ((uint32_t)((wt & 0x18u) == 0x18u) & (uint32_t)(r + 2 < n)) | ((uint32_t)((wt & 3u) == 3u) & (uint32_t)(r >= 2));
-                sw_hint = (int)((row_edge & h) | (col_edge & v));
-            }
+            TAFL_PROF_SPLIT(0);
             typename E::ApplyCtx ax;
-            E::apply_pre(st, m, C, ax, sw_hint);
-            // T layout upkeep: the move, then the (rare) captures
+            E::apply_pre(st, m, C, ax);
+            TAFL_PROF_SPLIT(4);
+            // T layout upkeep: the move, the custodial captures (V+- are +-1 here, H+- are +-W), then whatever else was
+            // captured (shieldwall, king, Linnaean: rare)
             {
-                const B fT = bit_at<NL>(n_to_t(m.from)), tT = bit_at<NL>(n_to_t(m.to));
-                defT = andn(defT, gate(fT, ax.mover != 0) | tT) | gate(tT, ax.mover != 0);
-                attT = andn(attT, gate(fT, ax.mover == 0) | tT) | gate(tT, ax.mover == 0);
-                B c = ax.caps;
-                while (any(c)) { const uint32_t i = lsb(c); c = andn(c, bit_at<NL>(i)); const B cb = bit_at<NL>(n_to_t(i)); attT = andn(attT, cb); defT = andn(defT, cb); }
+                constexpr int BK = 2 * W;
+                const uint32_t tT = n_to_t(m.to);
+                const B mvT = bit_at<NL>(n_to_t(m.from)) | bit_at<NL>(tT);
+                defT = defT ^ gate(mvT, ax.mover != 0); attT = attT ^ gate(mvT, ax.mover == 0);
+                const uint32_t cu = ax.cust;
+                const uint64_t cf = ((uint64_t)(cu & 1u) << (BK + 1)) | ((uint64_t)((cu >> 1) & 1u) << (BK - 1))
+                                  | ((uint64_t)((cu >> 2) & 1u) << (BK + W)) | ((uint64_t)((cu >> 3) & 1u) << (BK - W));
+                const B cT = deposit64<BK, NL>(cf, tT);
+                attT = andn(attT, cT); defT = andn(defT, cT);
+                if (ax.ncap != 0) TAFL_STAT_HIT(11);
+                if (ax.ncap != (uint32_t)__builtin_popcount(cu)) {
+                    TAFL_STAT_HIT(12);
+                    B c = ax.caps;
+                    while (any(c)) { const uint32_t i = lsb(c); c = andn(c, bit_at<NL>(i)); const B cb = bit_at<NL>(n_to_t(i)); attT = andn(attT, cb); defT = andn(defT, cb); }
+                }
             }
             // opponent's plays on the post-move board: no-plays test, enclosure filter, and the next ply's move set
+            TAFL_PROF_SPLIT(5);
             gen(st, attT, defT, ax.mover ^ 1u, C, fc, g);
+            TAFL_PROF_SPLIT(6);
             const bool skip_encl = ax.mover == 0 && C.rules.enclosure_win == TAFL_ENCL_WITHOUT_EDGE_ACCESS
                                    && (g.edge_hit || any(st.def & C.edge));
             const typename E::Outcome o = E::outcome_early(st, ax, C, skip_encl);
             E::apply_finish(st, ax, o, o.over ? 1u : g.total, C);
             ++ply;
+            TAFL_PROF_END(7);
         }
         E::finish_rollout(st, start_side, ply, stuck, res);
     }

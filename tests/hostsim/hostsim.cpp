@@ -128,3 +128,8 @@ int hs_rollout(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_st
 int hs_random_advance(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, uint64_t seed, const uint32_t* plies, uint64_t base) { DISPATCH(random_advance(r, n, st, cnt, seed, plies, base)) }
 int hs_mcts(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_mcts_params* p, uint64_t base, tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) { DISPATCH(mcts(r, n, st, cnt, p, base, out_children, max_children, out_n, stats)) }
 }
+
+#ifdef TAFL_STAT
+// statistics builds only (ablate experiments): event counters of the TAFL_STAT_HIT marks
+extern "C" { unsigned long long tafl_stat_acc[32] = {}; }
+#endif
