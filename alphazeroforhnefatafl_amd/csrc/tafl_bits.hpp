@@ -57,6 +57,21 @@ TAFL_HD bool wave_any(bool p) {
 #endif
 }
 
+// tile-index arithmetic with 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 are full rate on gfx950; the 32-bit
+// v_mul_lo_u32 / v_mul_hi_u32 a division by a constant compiles to are quarter rate).  Operands are tile indices (< 4694).
+TAFL_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
+template <int W> TAFL_HD uint32_t div_w(uint32_t x) {          // x / W, exact for x < 4694 (W in {7, 11, 15})
+    static_assert(W == 7 || W == 11 || W == 15, "div_w: reciprocal checked for these row widths only");
+    return mul24(x, 65536u / (uint32_t)W + 1u) >> 16;
+}
+template <int W> TAFL_HD uint32_t mod_w(uint32_t x) { return x - mul24(div_w<W>(x), (uint32_t)W); }
+
 template <int NL>
 struct Bits {
     uint32_t w[NL];

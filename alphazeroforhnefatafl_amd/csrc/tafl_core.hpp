@@ -105,7 +105,7 @@ struct Engine {
 
     static TAFL_HD uint32_t king_sq(const S& st, const K& C) {
         const uint32_t r = TAFL_F_KROW(st.flags), c = TAFL_F_KCOL(st.flags);
-        return (r < C.n && c < C.n) ? r * (uint32_t)W + c : TAFL_NO_SQ;
+        return (r < C.n && c < C.n) ? mul24(r, (uint32_t)W) + c : TAFL_NO_SQ;
     }
     // the tile that get_piece() reports as King: a defender standing on the nibble position
     // (game/board/state.rs:173-187, :24-26)
@@ -180,7 +180,7 @@ struct Engine {
         else { const B col = occ & col_mask(to % (uint32_t)W, C); from = (dir == 0) ? msb(col & lo) : lsb(col & hi); }
         Move m; m.from = from; m.to = to; m.dir = dir;
         const uint32_t d = to > from ? to - from : from - to;
-        m.dist = dir >= 2 ? d : d / (uint32_t)W;
+        m.dist = dir >= 2 ? d : div_w<W>(d);
         return m;
     }
     // idx-th play in ROLLOUT ORDER [build-defined, DESIGN.md]: direction-major V+,V-,H+,H-; inside a direction the
@@ -424,7 +424,7 @@ struct Engine {
     }
     static TAFL_HD B shieldwall(const S& st, uint32_t to, uint32_t mover, const K& C) {
         if (!C.rules.has_shieldwall) return bz<NL>();
-        const uint32_t r = to / (uint32_t)W, c = to % (uint32_t)W;
+        const uint32_t r = div_w<W>(to), c = mod_w<W>(to);
         bool horiz; int away;
         if (r == 0) { horiz = true; away = 1; } else if (r == C.n - 1) { horiz = true; away = -1; }
         else if (c == 0) { horiz = false; away = 1; } else if (c == C.n - 1) { horiz = false; away = -1; }
@@ -455,7 +455,7 @@ struct Engine {
         static_assert(BK <= 32 && 4 * W + 2 < 64, "field layout needs W <= 15");
         B caps = bz<NL>();
         uint32_t cust = 0;
-        const uint32_t to = m.to, r = to / (uint32_t)W, c = to % (uint32_t)W, n = C.n;
+        const uint32_t to = m.to, r = div_w<W>(to), c = mod_w<W>(to), n = C.n;
         const uint64_t fa = field64<BK>(st.att, to), fd = field64<BK>(st.def, to);
         const uint64_t fm = mover ? fd : fa, ft = mover ? fa : fd;
         const uint32_t kq = king_sq(st, C);
@@ -561,7 +561,7 @@ struct Engine {
 
     // ---- RepetitionTracker::track_play (game/game/state.rs:92-113) ------------------------------------------------
     static TAFL_HD void track(S& st, uint32_t mover, const Move& m, bool captured) {
-        const uint32_t fr = m.from / (uint32_t)W, fc = m.from % (uint32_t)W;
+        const uint32_t fr = div_w<W>(m.from), fc = mod_w<W>(m.from);
         const bool horiz = m.dir >= 2; const int disp = (m.dir & 1) ? -(int)m.dist : (int)m.dist;
         const uint32_t rec = TAFL_REP_PACK(mover, fr, fc, horiz, disp, captured);
         // branch-free: `hit` = this play repeats the one four plies back; every second hit counts (the mid-pair flag toggles);
@@ -596,7 +596,7 @@ struct Engine {
             const B mv = fbit | tbit;
             st.def = st.def ^ gate(mv, mover != 0);
             st.att = st.att ^ gate(mv, mover == 0);
-            const uint32_t r = m.to / (uint32_t)W, c = m.to % (uint32_t)W;
+            const uint32_t r = div_w<W>(m.to), c = mod_w<W>(m.to);
             const uint32_t kf = (st.flags & ~0x00FF0000u) | (r << 16) | (c << 20);
             st.flags = mover_is_king ? kf : st.flags;
         }

@@ -97,7 +97,7 @@ struct Fast {
         bool edge_hit;           // some play of the side lands on an edge tile
     };
 
-    static TAFL_HD uint32_t n_to_t(uint32_t idx) { return (idx % (uint32_t)W) * (uint32_t)W + idx / (uint32_t)W; }
+    static TAFL_HD uint32_t n_to_t(uint32_t idx) { const uint32_t q = div_w<W>(idx), m = idx - mul24(q, (uint32_t)W); return mul24(m, (uint32_t)W) + q; }
 
     // all rays in the +1 direction: attack set (first blocker included) of every slider at once
     static TAFL_HD B fill(const B& occ, const B& sliders, const B& vblock) {
@@ -146,10 +146,10 @@ struct Fast {
         const uint32_t x = nth_set_bit(rsel, idx);                       // destination, layout index
         const uint32_t s = msb(occ & below<NL>(x));                      // nearest piece behind it = the mover
         const uint32_t ux = odd ? Z - x : x, us = odd ? Z - s : s;       // un-reverse
-        const uint32_t qx = ux / (uint32_t)W, mx = ux % (uint32_t)W, qs = us / (uint32_t)W, ms = us % (uint32_t)W;
+        const uint32_t qx = div_w<W>(ux), mx = ux - mul24(qx, (uint32_t)W), qs = div_w<W>(us), ms = us - mul24(qs, (uint32_t)W);
         Move m;
-        m.to = horiz ? ux : mx * (uint32_t)W + qx;                       // T layout (col,row) -> N index
-        m.from = horiz ? us : ms * (uint32_t)W + qs;
+        m.to = horiz ? ux : mul24(mx, (uint32_t)W) + qx;                       // T layout (col,row) -> N index
+        m.from = horiz ? us : mul24(ms, (uint32_t)W) + qs;
         m.dir = d; m.dist = odd ? us - ux : ux - us;
         return m;
     }
