@@ -285,6 +285,8 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_policy(Consts<NL> C, MctsMe
 // --------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+// for the other translation units of the library (tafl_replay.cpp): same per-thread message as tafl_last_error()
+int tafl_fail_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(TAFL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
 
 enum { KC_MOVEGEN = 0, KC_STEP, KC_ROLLOUT, KC_MCTS_TREE, KC_MCTS_ROLLOUT, KC_MCTS_BACKUP, KC_COUNT };

@@ -314,6 +314,25 @@ int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visit
 int tafl_encode_boards(tafl_batch* b, uint8_t* out, int out_is_device);
 int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_device);
 
+/* ---- replay buffer on disk: write_to_file, game/main.rs:86-132 ------------------------
+ * Host-only, byte-exact text format of the reference: per record `side_len` lines of comma-separated matrix values, one line
+ * with the comma-separated vector, one line value1, one line value2; every line ends in '\n'.
+ * FIFO rule exactly as the reference implements it: the existing file is split into LINES, and if their number is
+ * >= max_entries ONE line (the first) is dropped before the new record is appended (main.rs:98-106) — the cap counts lines,
+ * not records.
+ *   tafl_replay_append        one record (one write_to_file call).
+ *   tafl_replay_append_batch  n records, identical to n consecutive tafl_replay_append calls in order, with one read and one
+ *                             write of the file.  matrices[n*side_len*side_len]; record g's vector is
+ *                             vectors[vector_offsets[g] .. vector_offsets[g+1]).
+ *   tafl_replay_read          (the reference has no reader) the newest <= max_records complete records, oldest first, parsed
+ *                             from the end of the file; vectors[k*vector_cap ..], vector_lens[k].  Any output may be NULL. */
+int tafl_replay_append(const char* path, const uint8_t* matrix, uint8_t side_len, const uint8_t* vector, uint32_t vector_len,
+                       uint8_t value1, uint8_t value2, uint64_t max_entries);
+int tafl_replay_append_batch(const char* path, const uint8_t* matrices, uint8_t side_len, uint32_t n, const uint8_t* vectors,
+                             const uint32_t* vector_offsets, const uint8_t* values1, const uint8_t* values2, uint64_t max_entries);
+int tafl_replay_read(const char* path, uint8_t side_len, uint32_t max_records, uint8_t* matrices, uint8_t* vectors, uint32_t vector_cap,
+                     uint32_t* vector_lens, uint8_t* values1, uint8_t* values2, uint32_t* out_n);
+
 /* ---- measurement helpers (bench.py) -----------------------------------------------------------------
  * HIP-event timing on the ctx stream: average duration of the named kernel class since the last reset.
  * classes: 0 movegen, 1 step, 2 rollout, 3 mcts_select_expand, 4 mcts_rollout, 5 mcts_backup */

@@ -458,3 +458,33 @@ def batch_mcts(logic: GameLogic, states, n: int, word_bits: int, params: TaflMct
     assert lib().orc_batch_mcts(logic.ptr, states, n, word_bits, C.byref(params), game_id_base, kids,
                                 max_children, cnt, C.byref(stats)) == 0
     return kids, cnt, stats
+
+
+# ---- replay buffer text format: write_to_file (game/main.rs:86-132), statement by statement ------------------------
+def write_to_file(file_path: str, matrix, vector, value1: int, value2: int, max_entries: int) -> None:
+    import os as _os
+    entries = []
+    if _os.path.exists(file_path):                                   # main.rs:98
+        with open(file_path, "r", newline="") as f:
+            content = f.read()                                       # read_to_string, main.rs:99
+        entries = _rust_lines(content)                               # content.lines(), main.rs:100
+    if len(entries) >= max_entries:                                  # main.rs:104
+        if entries:                                                  # Vec::remove(0) on an empty Vec would panic (max_entries == 0)
+            entries.pop(0)                                           # main.rs:105: the oldest LINE
+    new_entry = "{}\n{}\n{}\n{}".format(                             # main.rs:109-120
+        "\n".join(",".join(str(int(v)) for v in row) for row in matrix),
+        ",".join(str(int(v)) for v in vector), int(value1), int(value2))
+    entries.append(new_entry)                                        # main.rs:122
+    with open(file_path, "w", newline="") as f:                      # write + create + truncate, main.rs:125
+        for e in entries:
+            f.write(e + "\n")                                        # writeln!, main.rs:127-129
+
+
+def _rust_lines(s: str):
+    """str::lines(): split on '\\n', strip one trailing '\\r' per line, no empty element after a final newline."""
+    if not s:
+        return []
+    parts = s.split("\n")
+    if parts[-1] == "":
+        parts.pop()
+    return [p[:-1] if p.endswith("\r") else p for p in parts]
