@@ -88,6 +88,15 @@ def lib():
         sig("orc_rollout_order_plays", i32, vp, vp, P(TaflPlay), i32)
         sig("orc_rollout", i32, vp, vp, u64, u64, u32, u32, P(TaflRolloutResult))
         sig("orc_random_advance", i32, vp, vp, u64, u64, u32)
+        L._predict_t = C.CFUNCTYPE(None, vp, vp, P(C.c_float), P(C.c_float))
+        sig("orc_gmcts_new", vp, vp, vp, C.c_double, L._predict_t, vp)
+        sig("orc_gmcts_free", None, vp)
+        sig("orc_gmcts_run", i32, vp, u32)
+        sig("orc_gmcts_root_children", i32, vp, P(TaflRootChild), i32)
+        sig("orc_gmcts_root_ns", u32, vp)
+        sig("orc_gmcts_root_priors", i32, vp, P(C.c_double))
+        sig("orc_gmcts_counts", None, vp, P(u64))
+        sig("orc_np_sum", C.c_double, P(C.c_double), C.c_long)
         sig("orc_mcts_new", vp, vp, vp, P(TaflMctsParams), u64)
         sig("orc_mcts_free", None, vp)
         sig("orc_mcts_run", i32, vp)
@@ -219,6 +228,36 @@ class GameLogic:
         new = state.clone()
         lib().orc_random_advance(self.ptr, new.ptr, seed, game_id, plies)
         return new
+
+    def gmcts(self, state: "GameState", n_sims: int, c_puct: float, predict, word_bits: int):
+        """src/mcts.py:55-136 with an external predict(GameState) -> (priors float32[action_size], value).
+        Returns (children [(TaflPlay, action, visits, q)], Ns[root], root priors float64 list, counts)."""
+        L = lib()
+        A = int(L.orc_action_size(self.side_len))
+        size = int(L.orc_sizeof_state())
+
+        def cb(_ctx, st_ptr, pri_out, val_out):
+            g = GameState(None, word_bits=word_bits)
+            C.memmove(g._buf, st_ptr, size)
+            pri, v = predict(g)
+            for a in range(A):
+                pri_out[a] = float(pri[a])
+            val_out[0] = float(v)
+
+        fn = L._predict_t(cb)
+        m = L.orc_gmcts_new(self.ptr, state.ptr, c_puct, fn, None)
+        try:
+            L.orc_gmcts_run(m, n_sims)
+            buf = (TaflRootChild * 4096)()
+            n = L.orc_gmcts_root_children(m, buf, 4096)
+            kids = [(_copy_play(buf[i].play), int(buf[i].action), int(buf[i].visits), float(buf[i].q)) for i in range(n)]
+            pri = (C.c_double * A)()
+            L.orc_gmcts_root_priors(m, pri)
+            cnt = (C.c_uint64 * 4)()
+            L.orc_gmcts_counts(m, cnt)
+            return kids, int(L.orc_gmcts_root_ns(m)), list(pri), list(cnt)
+        finally:
+            L.orc_gmcts_free(m)
 
     def mcts(self, state: "GameState", n_sims: int, c_puct: float, seed: int, max_rollout_plies: int,
              game_id: int = 0, sim_offset: int = 0):

@@ -143,6 +143,18 @@ int  orc_mcts_root_children(const orc_mcts* m, tafl_root_child* out, int cap);
 uint32_t orc_mcts_root_ns(const orc_mcts* m);
 void orc_mcts_get_stats(const orc_mcts* m, tafl_mcts_stats* out);
 
+/* --- guided MCTS: src/mcts.py:55-136 with an external predict() (nnet.predict, mcts.py:85) ------------------------------ */
+typedef void (*orc_predict_fn)(void* ctx, const ostate* st, float* priors_out /* [action_size] */, float* value_out);
+typedef struct orc_gmcts orc_gmcts;
+orc_gmcts* orc_gmcts_new(const ologic* lg, const ostate* root, double c_puct, orc_predict_fn predict, void* ctx);
+void orc_gmcts_free(orc_gmcts* m);
+int  orc_gmcts_run(orc_gmcts* m, uint32_t n_sims);
+int  orc_gmcts_root_children(const orc_gmcts* m, tafl_root_child* out, int cap);
+uint32_t orc_gmcts_root_ns(const orc_gmcts* m);
+int  orc_gmcts_root_priors(const orc_gmcts* m, double* out);
+void orc_gmcts_counts(const orc_gmcts* m, uint64_t* out4);   /* sims, predicts, terminal hits, selection depth sum */
+double orc_np_sum(const double* a, long n);                  /* numpy's pairwise np.sum of a contiguous float64 array */
+
 /* --- batch drivers (differential tests at scale, cpu_baseline) ------------------------------------------------- */
 int orc_batch_movegen(const ologic* lg, const tafl_state* states, uint32_t n, uint32_t word_bits,
                       uint32_t* out_counts, uint32_t* out_masks, uint32_t mask_words);

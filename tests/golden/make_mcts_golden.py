@@ -28,6 +28,8 @@ import mcts as ref_mcts  # noqa: E402  the reference's src/mcts.py
 
 from alphazeroforhnefatafl_amd import abi  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from stub_net import matrix_bytes_of, stub_predict  # noqa: E402
 
 DRAW_VALUE = 1e-4   # alpha-zero-general convention for a drawn game (non-zero = ended)
 
@@ -86,6 +88,19 @@ class RolloutNet:
         return np.ones(self.game.getActionSize(), dtype=np.float64), float(r.value)
 
 
+class StubNet:
+    """nnet.predict = tests/stub_net.py on the board_to_matrix planes; the value is handed over as a Python float."""
+
+    def __init__(self, game, salt):
+        self.game, self.salt = game, salt
+        self.calls = 0
+
+    def predict(self, b):
+        self.calls += 1
+        pri, v = stub_predict(matrix_bytes_of(b.state.board_to_matrix()), int(b.state.side_to_play), self.game.getActionSize(), self.salt)
+        return pri, float(v)
+
+
 class Args:
     def __init__(self, n_sims, cpuct):
         self.numMCTSSims = n_sims
@@ -110,6 +125,49 @@ CASES = [
     dict(name="copenhagen13_start_48", rules="copenhagen", fen=abi.boards.COPENHAGEN13, side="starting", n_sims=48,
          cpuct=1.0, seed=9, game_id=0, max_plies=256),
 ]
+
+
+GUIDED_CASES = [
+    dict(name="guided_brandubh_400", rules="brandubh", fen=abi.boards.BRANDUBH, side="starting", n_sims=400, cpuct=1.0, salt=1),
+    dict(name="guided_copenhagen_start_150", rules="copenhagen", fen=abi.boards.COPENHAGEN, side="starting", n_sims=150, cpuct=1.0, salt=2),
+    dict(name="guided_copenhagen_midgame_250", rules="copenhagen", fen=None, advance=dict(seed=1, game_id=37, plies=37), side="starting",
+         n_sims=250, cpuct=2.5, salt=3),
+    dict(name="guided_tablut_200", rules="tablut", fen=abi.boards.TABLUT, side="starting", n_sims=200, cpuct=0.5, salt=4),
+    dict(name="guided_brandubh_near_escape_120", rules="brandubh", fen="7/7/3t3/2t4/7/5K1/3t3", side="D", n_sims=120, cpuct=1.0, salt=5),
+    dict(name="guided_copenhagen13_60", rules="copenhagen", fen=abi.boards.COPENHAGEN13, side="starting", n_sims=60, cpuct=1.0, salt=6),
+    dict(name="guided_masked_root_90", rules="brandubh", fen=abi.boards.BRANDUBH, side="starting", n_sims=90, cpuct=1.0, salt=None),
+]
+
+
+def run_guided_case(c):
+    rules = abi.rules.BY_NAME[c["rules"]]
+    side = rules.starting_side if c["side"] == "starting" else (abi.ATTACKER if c["side"] == "A" else abi.DEFENDER)
+    fen = c["fen"] or abi.boards.COPENHAGEN
+    n = abi.fen_side_len(fen)
+    wb = abi.word_bits_for(n)
+    logic = orc.GameLogic(rules, n)
+    st = orc.GameState(fen, side, wb)
+    if c.get("advance"):
+        a = c["advance"]
+        st = logic.random_advance(st, a["seed"], a["game_id"], a["plies"])
+    game = TaflGame(logic, n)
+    salt = c["salt"]
+    if salt is None:      # a salt for which the ROOT gets all-zero priors: the workaround branch at the root (mcts.py:91-98)
+        mb = matrix_bytes_of(st.board_to_matrix())
+        salt = next(x for x in range(256) if not stub_predict(mb, int(st.side_to_play), game.getActionSize(), x)[0].any())
+    net = StubNet(game, salt)
+    m = ref_mcts.MCTS(game, net, Args(c["n_sims"], c["cpuct"]))
+    root = Board(st, ())
+    probs = m.getActionProb(root, temp=1)
+    s = game.stringRepresentation(root)
+    children = [[a, int(m.Nsa[(s, a)]), float(m.Qsa[(s, a)]).hex()] for a in range(game.getActionSize()) if (s, a) in m.Nsa]
+    out = dict(c)
+    out.update(salt=salt, fen=st.to_fen(), side_to_play=int(st.side_to_play), state_hex=bytes(st.to_abi()).hex(), word_bits=wb, side_len=n,
+               root_ns=int(m.Ns[s]), root_children=children, n_tree_states=len(m.Ps), predict_calls=net.calls,
+               n_terminal_states=sum(1 for v in m.Es.values() if v != 0),
+               root_priors_nonzero=[(i, float(p).hex()) for i, p in enumerate(m.Ps[s]) if p != 0],
+               probs_temp1_nonzero=[(i, float(p).hex()) for i, p in enumerate(probs) if p != 0])
+    return out
 
 
 def run_case(c):
@@ -151,9 +209,14 @@ def run_case(c):
 def main():
     res = dict(_comment="Generated by tests/golden/make_mcts_golden.py from the reference's src/mcts.py "
                         "(MCTS.getActionProb/search) over the oracle adaptor. Qsa/probs are float.hex().",
-               draw_value=DRAW_VALUE, cases=[run_case(c) for c in CASES])
+               draw_value=DRAW_VALUE, cases=[run_case(c) for c in CASES],
+               guided_comment="guided_cases: the same reference MCTS with nnet.predict = tests/stub_net.py (non-uniform float32 priors, "
+                              "value passed as a Python float); root_priors_nonzero = Ps[root] after masking / renormalising.",
+               guided_cases=[run_guided_case(c) for c in GUIDED_CASES])
     with open(os.path.join(HERE, "mcts_golden.json"), "w") as f:
         json.dump(res, f, indent=1)
+    for c in res["guided_cases"]:
+        print(c["name"], "Ns", c["root_ns"], "children", len(c["root_children"]), "states", c["n_tree_states"], "terminal", c["n_terminal_states"])
     for c in res["cases"]:
         print(c["name"], "Ns", c["root_ns"], "children", len(c["root_children"]), "states", c["n_tree_states"],
               "terminal", c["n_terminal_states"])

@@ -52,3 +52,39 @@ def test_config1_plumbing_reports_rate():
     dt = time.perf_counter() - t0
     assert root_ns == 999 and stats.rollouts == 1000
     print(f"config1: {1000 / dt:.0f} sims/s, {stats.rollout_plies / dt:.0f} rollout plies/s on 1 CPU thread")
+
+
+# ---- guided mode: nnet.predict with non-uniform priors (tests/stub_net.py) -----------------------------------------------
+from tests.stub_net import matrix_bytes_of, stub_predict  # noqa: E402
+
+
+def stub_for(case, action_size):
+    def predict(gs):
+        return stub_predict(matrix_bytes_of(gs.board_to_matrix()), int(gs.side_to_play), action_size, case["salt"])
+    return predict
+
+
+@pytest.mark.parametrize("case", GOLD["guided_cases"], ids=[c["name"] for c in GOLD["guided_cases"]])
+def test_c_guided_mcts_matches_reference_mcts_py(case):
+    """The literal guided restatement (gm_search: dense Ps / Vs, numpy's pairwise np.sum) against the reference's mcts.py."""
+    logic = orc.GameLogic(abi.rules.BY_NAME[case["rules"]], case["side_len"])
+    st = state_from_case(case)
+    A = abi.action_size(case["side_len"])
+    kids, root_ns, pri, counts = logic.gmcts(st, case["n_sims"], case["cpuct"], stub_for(case, A), case["word_bits"])
+    assert root_ns == case["root_ns"]
+    assert [[a, n, float(q).hex()] for (_p, a, n, q) in kids] == case["root_children"]
+    assert [(i, float(p).hex()) for i, p in enumerate(pri) if p != 0] == [tuple(x) for x in case["root_priors_nonzero"]]
+    assert counts[0] == case["n_sims"] and counts[1] == case["predict_calls"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 100, 127, 128, 129, 255, 256, 257, 1000, 2420, 4056, 8000])
+def test_np_sum_restatement_is_numpys(n):
+    """orc_np_sum (numpy's pairwise summation restated) == np.sum bit for bit, on values whose sum rounds."""
+    import numpy as np
+    rs = np.random.RandomState(n)
+    for trial in range(4):
+        a = np.ldexp(rs.randint(1 << 23, 1 << 24, size=n).astype(np.float64), -24 - rs.randint(0, 40, size=n))
+        if trial == 1:
+            a[rs.randint(0, 2, size=n) == 0] = 0.0
+        buf = (C.c_double * max(1, n))(*a.tolist())
+        assert orc.lib().orc_np_sum(buf, n) == float(np.sum(a)), (n, trial)
