@@ -6,7 +6,7 @@ thousands of concurrent games) as hand-written HIP kernels behind a C-ABI (inclu
 from . import abi
 from .abi import Ruleset, boards, rules
 
-__all__ = ["abi", "Ruleset", "boards", "rules", "BatchedGameLogic", "GameBatch", "MCTS", "MCTSArgs"]
+__all__ = ["abi", "Ruleset", "boards", "rules", "BatchedGameLogic", "GameBatch", "MCTS", "MCTSArgs", "GuidedMCTS"]
 
 
 def __getattr__(name):
@@ -14,7 +14,7 @@ def __getattr__(name):
     if name in ("BatchedGameLogic", "GameBatch"):
         from . import engine
         return getattr(engine, name)
-    if name in ("MCTS", "MCTSArgs"):
+    if name in ("MCTS", "MCTSArgs", "GuidedMCTS"):
         from . import mcts
         return getattr(mcts, name)
     raise AttributeError(name)

@@ -6,7 +6,7 @@ import os
 import subprocess
 
 from . import abi
-from .abi import (TaflEffects, TaflMctsParams, TaflMctsStats, TaflPlay, TaflRolloutResult, TaflRootChild, TaflRules,
+from .abi import (TaflEffects, TaflGmctsStats, TaflMctsParams, TaflMctsStats, TaflPlay, TaflRolloutResult, TaflRootChild, TaflRules,
                   TaflState)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -51,6 +51,13 @@ SYMBOLS = [
     ("tafl_mcts_best_play", _i32, [_vp, _P(TaflPlay), _P(_u32)]),
     ("tafl_encode_boards", _i32, [_vp, _vp, _i32]),
     ("tafl_mcts_policy_device", _i32, [_vp, _dbl, _vp, _i32]),
+    ("tafl_gmcts_begin", _i32, [_vp, _u32, _u32]),
+    ("tafl_gmcts_step", _i32, [_vp, _vp, _vp, _i32, _dbl, _u32, _P(_u32)]),
+    ("tafl_gmcts_leaves", _i32, [_vp, _vp, _vp, _vp, _i32]),
+    ("tafl_gmcts_root_children", _i32, [_vp, _P(TaflRootChild), _u32, _P(_u32)]),
+    ("tafl_gmcts_root_visits", _i32, [_vp, _vp, _i32]),
+    ("tafl_gmcts_policy", _i32, [_vp, _dbl, _vp, _i32]),
+    ("tafl_gmcts_get_stats", _i32, [_vp, _P(TaflGmctsStats)]),
     ("tafl_replay_append", _i32, [C.c_char_p, _P(_u8), _u8, _P(_u8), _u32, _u8, _u8, _u64]),
     ("tafl_replay_append_batch", _i32, [C.c_char_p, _P(_u8), _u8, _u32, _P(_u8), _P(_u32), _P(_u8), _P(_u8), _u64]),
     ("tafl_replay_read", _i32, [C.c_char_p, _u8, _u32, _P(_u8), _P(_u8), _u32, _P(_u32), _P(_u8), _P(_u8), _P(_u32)]),

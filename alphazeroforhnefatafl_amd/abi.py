@@ -134,13 +134,18 @@ class TaflMctsStats(C.Structure):
                 ("spec_hits", C.c_uint64)]
 
 
+class TaflGmctsStats(C.Structure):
+    _fields_ = [("sims", C.c_uint64), ("predicts", C.c_uint64), ("terminal_hits", C.c_uint64), ("faults", C.c_uint64),
+                ("select_depth_sum", C.c_uint64), ("waiting", C.c_uint64), ("_reserved", C.c_uint64 * 2)]
+
+
 EXPECTED_SIZES = {"tafl_rules": 32, "tafl_play": 4, "tafl_state": 104, "tafl_effects": 40,
                   "tafl_rollout_result": 8, "tafl_root_child": 24, "tafl_mcts_params": 32,
-                  "tafl_mcts_stats": 200}
+                  "tafl_mcts_stats": 200, "tafl_gmcts_stats": 64}
 for _name, _cls in [("tafl_rules", TaflRules), ("tafl_play", TaflPlay), ("tafl_state", TaflState),
                     ("tafl_effects", TaflEffects), ("tafl_rollout_result", TaflRolloutResult),
                     ("tafl_root_child", TaflRootChild), ("tafl_mcts_params", TaflMctsParams),
-                    ("tafl_mcts_stats", TaflMctsStats)]:
+                    ("tafl_mcts_stats", TaflMctsStats), ("tafl_gmcts_stats", TaflGmctsStats)]:
     assert C.sizeof(_cls) == EXPECTED_SIZES[_name], (_name, C.sizeof(_cls))
 
 

@@ -17,6 +17,7 @@
 
 #include "tafl_host.hpp"
 #include "tafl_ops.hpp"
+#include "tafl_guided.hpp"
 
 using namespace tafl;
 
@@ -331,6 +332,9 @@ struct tafl_batch {
     DevBuf sim_next, spec_state, spec_value, spec_kind, spec_reason, spec_plies, spec_parent, spec_o0, spec_first, spec_n;
     uint32_t spec_k, spec_cooldown;
     tafl_mcts_stats last_stats; bool ran;
+    // guided MCTS (external evaluator)
+    GuidedMem gmem; bool g_has; uint32_t g_max_sims;
+    DevBuf g_node_state, g_hdr, g_pedge, g_edges, g_node_top, g_edge_top, g_leaf, g_kind, g_fault, g_sims, g_stats, g_priors, g_values, g_boards, g_sides, g_wait;
 };
 
 static int quads_of(const tafl_ctx* c) { return (2 * (int)c->nl + 8) / 4; }
@@ -466,7 +470,7 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     HIPCHK(hipSetDevice(c->device));
     tafl_batch* b = new (std::nothrow) tafl_batch();
     if (!b) return fail(TAFL_ERR_OOM, "out of host memory");
-    b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr;
+    b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr; b->g_has = false; b->g_max_sims = 0;
     { const char* e = getenv("TAFL_SPEC_K"); int k = e ? atoi(e) : 2; b->spec_k = (uint32_t)(k < 1 ? 1 : (k > 8 ? 8 : k)); }
     { const char* e = getenv("TAFL_SPEC_COOLDOWN"); int v = e ? atoi(e) : 0; b->spec_cooldown = (uint32_t)(v < 0 ? 0 : (v > 200 ? 200 : v)); }
     memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats);
@@ -485,7 +489,9 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->spec_cool};
+                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->spec_cool,
+                      &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
+                      &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return TAFL_OK;
@@ -881,6 +887,195 @@ int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_
     HIPCHK(hipGetLastError());
     if (!out_is_device) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+}  // extern "C"
+
+// ---- guided MCTS: external evaluator (tafl_guided.hpp) -------------------------------------------------------------------
+enum { GS_SIMS = 0, GS_PREDICTS, GS_TERMINAL, GS_FAULTS, GS_DEPTH, GS_WAITING, GS_COUNT };
+
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_gmcts_init(Consts<NL> C, const Quad* soa, GuidedMem M) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, M.G, g, st);
+    Guided<NL, W>::init_game(M, g, st);
+}
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_gmcts_step(Consts<NL> C, GuidedMem M, const float* priors, const float* values, uint32_t A, double c_puct,
+                                                           uint32_t n_sims, unsigned long long* stats) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    GuidedStats gs; gs.sims = gs.predicts = gs.terminal_hits = gs.faults = gs.depth = 0;
+    Guided<NL, W>::step(M, g, priors ? priors + (size_t)g * A : nullptr, values ? values[g] : 0.f, A, c_puct, n_sims, C, gs);
+    if (gs.sims) atomicAdd(&stats[GS_SIMS], (unsigned long long)gs.sims);
+    if (gs.predicts) atomicAdd(&stats[GS_PREDICTS], (unsigned long long)gs.predicts);
+    if (gs.terminal_hits) atomicAdd(&stats[GS_TERMINAL], (unsigned long long)gs.terminal_hits);
+    if (gs.faults) atomicAdd(&stats[GS_FAULTS], (unsigned long long)gs.faults);
+    if (gs.depth) atomicAdd(&stats[GS_DEPTH], (unsigned long long)gs.depth);
+    if (M.kind[g] == 1) atomicAdd(&stats[GS_WAITING], 1ull);
+}
+// network input of the waiting leaves: board_to_matrix planes (game/main.rs:55-83), side to move, waiting flag; one thread per tile
+template <int NL, int W>
+__global__ __launch_bounds__(256) void k_gmcts_leaves(Consts<NL> C, GuidedMem M, uint8_t* boards, uint8_t* sides, uint8_t* waiting) {
+    const uint32_t nn = C.n * C.n;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M.G * nn) return;
+    const uint32_t g = (uint32_t)(i / nn), t = (uint32_t)(i % nn), r = t / C.n, c = t % C.n, bit = r * (uint32_t)W + c;
+    const bool wait = M.kind[g] == 1;
+    const uint32_t L = wait ? M.leaf[g] : 0u;
+    const uint32_t* rec = (const uint32_t*)(M.node_state + ((size_t)L * M.G + g) * StateIO<NL>::QUADS);   // att[NL], def[NL], rep[4], meta[4]
+    const uint32_t aw = rec[bit >> 5], dw = rec[NL + (bit >> 5)], flags = rec[2 * NL + 7];
+    uint32_t v = 0;
+    if ((r == 0 || r == C.n - 1) && (c == 0 || c == C.n - 1)) v = 20;
+    if (r == C.n / 2 && c == C.n / 2) v = 30;
+    const bool d = (dw >> (bit & 31)) & 1u, a = (aw >> (bit & 31)) & 1u;
+    if (d) v += (r == TAFL_F_KROW(flags) && c == TAFL_F_KCOL(flags)) ? 5u : 1u; else if (a) v += 1u;
+    boards[i] = (uint8_t)v;
+    if (t == 0) { sides[g] = (uint8_t)((flags & TAFL_F_SIDE) ? TAFL_DEFENDER : TAFL_ATTACKER); waiting[g] = wait ? 1 : 0; }
+}
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_gmcts_root_children(Consts<NL> C, GuidedMem M, tafl_root_child* out, uint32_t max_children, uint32_t* out_n) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    out_n[g] = Guided<NL, W>::root_children(M, g, out + (size_t)g * max_children, max_children);
+}
+// dense root visit counts and the probs of src/mcts.py:48-53 (temp 1: counts / float(sum), temp 0: one-hot on the first maximum)
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_gmcts_root_dense(Consts<NL> C, GuidedMem M, uint32_t* visits, double* probs, uint32_t A, int one_hot) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    const GNode h = M.hdr[g];
+    if (!h.expanded) return;
+    const GEdge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+    double sum = 0.0; uint32_t best = 0, arg = 0; bool any_n = false;
+    for (uint32_t j = 0; j < h.n_legal; ++j) { const GEdge e = eb[j]; sum += (double)e.n; if (e.n > best) { best = e.n; arg = j; } any_n |= e.n != 0; }
+    for (uint32_t j = 0; j < h.n_legal; ++j) {
+        const GEdge e = eb[j];
+        if (visits) visits[(size_t)g * A + e.action] = e.n;
+        if (probs && any_n) probs[(size_t)g * A + e.action] = one_hot ? (j == arg ? 1.0 : 0.0) : (double)e.n / sum;
+    }
+}
+
+extern "C" {
+
+int tafl_gmcts_begin(tafl_batch* b, uint32_t max_sims, uint32_t edges_per_node) {
+    if (!b || max_sims == 0 || edges_per_node == 0) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_begin: bad argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n; const size_t q = (size_t)quads_of(c);
+    HIPCHK(hipSetDevice(c->device));
+    const uint32_t node_cap = max_sims + 1;
+    const unsigned long long ecap = (unsigned long long)node_cap * edges_per_node;
+    if (ecap > 0xFFFFFFFFull) return fail(TAFL_ERR_CAPACITY, "tafl_gmcts_begin: edge arena too large");
+    NEED(b->g_node_state, sizeof(Quad) * q * node_cap * n); NEED(b->g_hdr, sizeof(GNode) * (size_t)node_cap * n);
+    NEED(b->g_pedge, sizeof(uint32_t) * (size_t)node_cap * n); NEED(b->g_edges, sizeof(GEdge) * (size_t)ecap * n);
+    NEED(b->g_node_top, 4 * (size_t)n); NEED(b->g_edge_top, 4 * (size_t)n); NEED(b->g_leaf, 4 * (size_t)n); NEED(b->g_kind, n); NEED(b->g_fault, n);
+    NEED(b->g_sims, 4 * (size_t)n); NEED(b->g_stats, sizeof(unsigned long long) * GS_COUNT);
+    GuidedMem& M = b->gmem;
+    M.node_state = (Quad*)b->g_node_state.p; M.hdr = (GNode*)b->g_hdr.p; M.pedge = (uint32_t*)b->g_pedge.p; M.edges = (GEdge*)b->g_edges.p;
+    M.node_top = (uint32_t*)b->g_node_top.p; M.edge_top = (uint32_t*)b->g_edge_top.p; M.leaf = (uint32_t*)b->g_leaf.p; M.kind = (uint8_t*)b->g_kind.p;
+    M.fault = (uint8_t*)b->g_fault.p; M.sims_done = (uint32_t*)b->g_sims.p; M.G = n; M.node_cap = node_cap; M.edge_cap = (uint32_t)ecap;
+    HIPCHK(hipMemsetAsync(b->g_stats.p, 0, sizeof(unsigned long long) * GS_COUNT, c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_gmcts_init<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, M));
+    HIPCHK(hipGetLastError());
+    b->g_has = true; b->g_max_sims = max_sims;
+    return TAFL_OK;
+}
+
+int tafl_gmcts_step(tafl_batch* b, const float* priors, const float* values, int in_is_device, double c_puct, uint32_t n_sims, uint32_t* out_waiting) {
+    if (!b || !b->g_has) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_step: tafl_gmcts_begin first");
+    if (n_sims > b->g_max_sims) return fail(TAFL_ERR_CAPACITY, "tafl_gmcts_step: n_sims exceeds the reserved simulations");
+    if ((priors == nullptr) != (values == nullptr)) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_step: priors and values go together");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n, A = tafl_action_size(c);
+    HIPCHK(hipSetDevice(c->device));
+    const float* dp = priors; const float* dv = values;
+    if (priors && !in_is_device) {
+        NEED(b->g_priors, sizeof(float) * (size_t)n * A); NEED(b->g_values, sizeof(float) * (size_t)n);
+        HIPCHK(hipMemcpyAsync(b->g_priors.p, priors, sizeof(float) * (size_t)n * A, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(b->g_values.p, values, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        dp = (const float*)b->g_priors.p; dv = (const float*)b->g_values.p;
+    }
+    unsigned long long* st = (unsigned long long*)b->g_stats.p;
+    HIPCHK(hipMemsetAsync(st + GS_WAITING, 0, sizeof(unsigned long long), c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_gmcts_step<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->gmem, dp, dv, A, c_puct, n_sims, st));
+    HIPCHK(hipGetLastError());
+    if (out_waiting) {
+        unsigned long long w = 0;
+        HIPCHK(hipMemcpyAsync(&w, st + GS_WAITING, sizeof w, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *out_waiting = (uint32_t)w;
+    }
+    return TAFL_OK;
+}
+
+int tafl_gmcts_leaves(tafl_batch* b, uint8_t* boards, uint8_t* sides, uint8_t* waiting, int out_is_device) {
+    if (!b || !b->g_has || !boards || !sides || !waiting) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_leaves: bad argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n; const size_t total = (size_t)n * c->n * c->n;
+    HIPCHK(hipSetDevice(c->device));
+    uint8_t *db = boards, *ds = sides, *dw = waiting;
+    if (!out_is_device) { NEED(b->g_boards, total); NEED(b->g_sides, n); NEED(b->g_wait, n); db = (uint8_t*)b->g_boards.p; ds = (uint8_t*)b->g_sides.p; dw = (uint8_t*)b->g_wait.p; }
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_gmcts_leaves<NL, W>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, CC, b->gmem, db, ds, dw));
+    HIPCHK(hipGetLastError());
+    if (!out_is_device) {
+        HIPCHK(hipMemcpyAsync(boards, db, total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(sides, ds, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(waiting, dw, n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_gmcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_children, uint32_t* out_n) {
+    if (!b || !b->g_has || !out || !out_n || max_children == 0) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_root_children: bad argument");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    NEED(b->children, sizeof(tafl_root_child) * (size_t)n * max_children); NEED(b->children_n, sizeof(uint32_t) * n);
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_gmcts_root_children<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->gmem, (tafl_root_child*)b->children.p,
+                                       max_children, (uint32_t*)b->children_n.p));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, b->children.p, sizeof(tafl_root_child) * (size_t)n * max_children, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(out_n, b->children_n.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (uint32_t g = 0; g < n; ++g) if (out_n[g] > max_children) return fail(TAFL_ERR_CAPACITY, "tafl_gmcts_root_children: max_children too small");
+    return TAFL_OK;
+}
+
+static int gmcts_dense(tafl_batch* b, uint32_t* visits, double* probs, double temp, int out_is_device) {
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n, A = tafl_action_size(c);
+    HIPCHK(hipSetDevice(c->device));
+    const size_t vb = sizeof(uint32_t) * (size_t)n * A, pb = sizeof(double) * (size_t)n * A;
+    uint32_t* dv = visits; double* dp = probs;
+    if (!out_is_device) { if (visits) { NEED(b->visits, vb); dv = (uint32_t*)b->visits.p; } if (probs) { NEED(b->policy, pb); dp = (double*)b->policy.p; } }
+    if (dv) HIPCHK(hipMemsetAsync(dv, 0, vb, c->stream));
+    if (dp) HIPCHK(hipMemsetAsync(dp, 0, pb, c->stream));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_gmcts_root_dense<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->gmem, dv, dp, A, temp == 0.0 ? 1 : 0));
+    HIPCHK(hipGetLastError());
+    if (!out_is_device) {
+        if (visits) HIPCHK(hipMemcpyAsync(visits, dv, vb, hipMemcpyDeviceToHost, c->stream));
+        if (probs) HIPCHK(hipMemcpyAsync(probs, dp, pb, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+int tafl_gmcts_root_visits(tafl_batch* b, uint32_t* out, int out_is_device) {
+    if (!b || !b->g_has || !out) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_root_visits: bad argument");
+    return gmcts_dense(b, out, nullptr, 1.0, out_is_device);
+}
+int tafl_gmcts_policy(tafl_batch* b, double temp, double* out, int out_is_device) {
+    if (!b || !b->g_has || !out) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_policy: bad argument");
+    if (!(temp == 0.0 || temp == 1.0)) return fail(TAFL_ERR_UNSUPPORTED, "tafl_gmcts_policy supports temp 0 and 1");
+    return gmcts_dense(b, nullptr, out, temp, out_is_device);
+}
+int tafl_gmcts_get_stats(tafl_batch* b, tafl_gmcts_stats* out) {
+    if (!b || !b->g_has || !out) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_get_stats: bad argument");
+    tafl_ctx* c = b->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    unsigned long long h[GS_COUNT];
+    HIPCHK(hipMemcpyAsync(h, b->g_stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memset(out, 0, sizeof *out);
+    out->sims = h[GS_SIMS]; out->predicts = h[GS_PREDICTS]; out->terminal_hits = h[GS_TERMINAL]; out->faults = h[GS_FAULTS];
+    out->select_depth_sum = h[GS_DEPTH]; out->waiting = h[GS_WAITING];
     return TAFL_OK;
 }
 

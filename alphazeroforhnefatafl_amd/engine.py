@@ -12,7 +12,7 @@ import ctypes as C
 
 from . import abi
 from ._lib import check, lib
-from .abi import (TaflEffects, TaflMctsParams, TaflMctsStats, TaflPlay, TaflRolloutResult, TaflRootChild, TaflState)
+from .abi import (TaflEffects, TaflGmctsStats, TaflMctsParams, TaflMctsStats, TaflPlay, TaflRolloutResult, TaflRootChild, TaflState)
 
 KC_MOVEGEN, KC_STEP, KC_ROLLOUT, KC_MCTS_TREE, KC_MCTS_ROLLOUT, KC_MCTS_BACKUP = range(6)
 
@@ -203,6 +203,57 @@ class GameBatch:
         out = (C.c_double * (self.n * self.logic.action_size))()
         check(lib().tafl_mcts_policy_device(self._h, temp, C.cast(out, C.c_void_p), 0))
         return out
+
+    # -- guided MCTS: the caller's network is nnet.predict (src/mcts.py:85) --------------------------------------------
+    def gmcts_begin(self, max_sims: int, edges_per_node: int = 256):
+        check(lib().tafl_gmcts_begin(self._h, max_sims, edges_per_node))
+
+    def gmcts_step(self, priors=None, values=None, c_puct: float = 1.0, n_sims: int = 64, device: bool = False, want_waiting: bool = True) -> int:
+        """Expand the waiting leaves with (priors float32 [n, action_size], values float32 [n]) and select the next ones.
+        `priors` / `values`: ctypes float arrays (host) or integer device pointers (device=True).  Returns the games now waiting."""
+        w = C.c_uint32()
+        pp = C.c_void_p(priors) if isinstance(priors, int) else (C.cast(priors, C.c_void_p) if priors is not None else None)
+        pv = C.c_void_p(values) if isinstance(values, int) else (C.cast(values, C.c_void_p) if values is not None else None)
+        check(lib().tafl_gmcts_step(self._h, pp, pv, int(device), c_puct, n_sims, C.byref(w) if want_waiting else None))
+        return w.value
+
+    def gmcts_leaves(self, boards_ptr: int | None = None, sides_ptr: int | None = None, waiting_ptr: int | None = None):
+        """Network input of the waiting leaves: (boards uint8 [n, side, side], sides uint8 [n], waiting uint8 [n]); with device
+        pointers nothing crosses PCIe, otherwise host ctypes arrays are returned."""
+        if boards_ptr is not None:
+            check(lib().tafl_gmcts_leaves(self._h, C.c_void_p(boards_ptr), C.c_void_p(sides_ptr), C.c_void_p(waiting_ptr), 1))
+            return None
+        n, s = self.n, self.logic.side_len
+        boards, sides, waiting = (C.c_uint8 * (n * s * s))(), (C.c_uint8 * n)(), (C.c_uint8 * n)()
+        check(lib().tafl_gmcts_leaves(self._h, C.cast(boards, C.c_void_p), C.cast(sides, C.c_void_p), C.cast(waiting, C.c_void_p), 0))
+        return boards, sides, waiting
+
+    def gmcts_root_children(self, max_children: int = 512):
+        kids = (TaflRootChild * (self.n * max_children))()
+        cnt = (C.c_uint32 * self.n)()
+        check(lib().tafl_gmcts_root_children(self._h, kids, max_children, cnt))
+        return kids, cnt
+
+    def gmcts_root_visits(self, out_device_ptr: int | None = None):
+        if out_device_ptr is not None:
+            check(lib().tafl_gmcts_root_visits(self._h, C.c_void_p(out_device_ptr), 1))
+            return None
+        out = (C.c_uint32 * (self.n * self.logic.action_size))()
+        check(lib().tafl_gmcts_root_visits(self._h, C.cast(out, C.c_void_p), 0))
+        return out
+
+    def gmcts_policy(self, temp: float = 1.0, out_device_ptr: int | None = None):
+        if out_device_ptr is not None:
+            check(lib().tafl_gmcts_policy(self._h, temp, C.c_void_p(out_device_ptr), 1))
+            return None
+        out = (C.c_double * (self.n * self.logic.action_size))()
+        check(lib().tafl_gmcts_policy(self._h, temp, C.cast(out, C.c_void_p), 0))
+        return out
+
+    def gmcts_stats(self) -> TaflGmctsStats:
+        st = TaflGmctsStats()
+        check(lib().tafl_gmcts_get_stats(self._h, C.byref(st)))
+        return st
 
     def mcts_best_play(self):
         plays = (TaflPlay * self.n)()

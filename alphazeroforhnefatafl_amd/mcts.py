@@ -2,8 +2,9 @@
 
 `MCTS(game_batch, args).getActionProb(temp)` runs `args.numMCTSSims` simulations for every game of
 the batch on the GPU (select / expand / random-rollout / backup as lock-step HIP kernels) and returns the
-policy vectors of src/mcts.py:40-53.  `predict` is fixed to the random-rollout mode of SURVEY.md §8a:
-uniform priors over legal plays + the value of one seeded random playout.
+policy vectors of src/mcts.py:40-53.  Without a network, `predict` is the random-rollout mode of SURVEY.md §8a (uniform priors over legal plays + the value of
+one seeded random playout).  With `nnet`, `predict` is the caller's network evaluated for the whole batch at once
+(`GuidedMCTS`, include/taflhip.h "guided MCTS"): nnet.predict_batch(boards, sides, waiting) -> (priors, values).
 """
 from __future__ import annotations
 
@@ -49,3 +50,44 @@ class MCTS:
         if not self._ran:
             self.search_all()
         return self.batch.mcts_best_play()
+
+
+class GuidedMCTS:
+    """src/mcts.py:11-136 with `nnet` as the evaluator, for every game of the batch in lock step.
+
+    `nnet.predict_batch(boards, sides, waiting)` receives the network input of the waiting leaves — the
+    board_to_matrix planes uint8 [n, side, side] (game/main.rs:55-83), the side to move [n] and a waiting flag [n] — and
+    returns (priors float32 [n, action_size], values float32 [n]); rows of games that are not waiting are ignored.
+    With `device=True` the three inputs are integer device pointers into buffers the caller allocated
+    (`buffers=(boards_ptr, sides_ptr, waiting_ptr)`) and the outputs are device pointers too: nothing crosses PCIe.
+    """
+
+    def __init__(self, batch: GameBatch, nnet, args: MCTSArgs, edges_per_node: int = 256, device: bool = False, buffers=None):
+        self.batch, self.nnet, self.args = batch, nnet, args
+        self.edges_per_node, self.device, self.buffers = edges_per_node, device, buffers
+        self.rounds = 0
+        self._ran = False
+
+    def search_all(self):
+        a, b = self.args, self.batch
+        b.gmcts_begin(a.numMCTSSims, self.edges_per_node)
+        waiting = b.gmcts_step(None, None, a.cpuct, a.numMCTSSims)
+        while waiting:
+            if self.device:
+                b.gmcts_leaves(*self.buffers)
+                priors, values = self.nnet.predict_batch(*self.buffers)
+            else:
+                priors, values = self.nnet.predict_batch(*b.gmcts_leaves())
+            waiting = b.gmcts_step(priors, values, a.cpuct, a.numMCTSSims, device=self.device)
+            self.rounds += 1
+        self._ran = True
+
+    def getActionProb(self, temp: float = 1.0):
+        """src/mcts.py:28-53 per game: flat float64 [n_games * action_size] (temp 0: first maximum)."""
+        self.search_all()
+        return self.batch.gmcts_policy(temp)
+
+    def root_children(self, max_children: int = 512):
+        if not self._ran:
+            self.search_all()
+        return self.batch.gmcts_root_children(max_children)

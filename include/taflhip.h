@@ -314,6 +314,32 @@ int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visit
 int tafl_encode_boards(tafl_batch* b, uint8_t* out, int out_is_device);
 int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_device);
 
+/* ---- guided MCTS: src/mcts.py:55-136 with the CALLER's network as nnet.predict (mcts.py:85), SURVEY.md section 8f rank 3 ---
+ * Lock-step over the batch: each tafl_gmcts_step (i) expands every waiting leaf with the priors / value the caller computed
+ * for it (mask by the legal moves, renormalise with numpy's pairwise np.sum, all-masked workaround: mcts.py:86-98) and backs
+ * the value up (mcts.py:127-136), then (ii) runs searches from the root until one reaches a state that needs predict();
+ * searches that end in a terminal state are completed on the way.  A game is done after n_sims searches.
+ *   priors  float32 [n * tafl_action_size], row g = network policy for game g's waiting leaf (rows of games that are not
+ *           waiting are ignored); widened to float64 by the masking multiply as in mcts.py:87.
+ *   values  float32 [n], used as Python floats (float(v)).
+ *   first call after tafl_gmcts_begin: priors = values = NULL.  out_waiting (may be NULL) = games now waiting for predict().
+ * tafl_gmcts_leaves: the network input for the waiting leaves: board_to_matrix planes uint8 [n * side_len * side_len]
+ *   (game/main.rs:55-83), side to move [n] (TAFL_ATTACKER / TAFL_DEFENDER), waiting flag [n].
+ * Device pointers (in_is_device / out_is_device = 1, e.g. torch tensors) keep the whole loop off PCIe.
+ * tafl_gmcts_begin sizes the arena: max_sims + 1 nodes and (max_sims + 1) * edges_per_node edges per game (one edge per LEGAL
+ * move of every expanded node); a game that outgrows it raises its fault flag and stops searching (stats.faults). */
+typedef struct tafl_gmcts_stats {
+    uint64_t sims, predicts, terminal_hits, faults, select_depth_sum, waiting, _reserved[2];
+} tafl_gmcts_stats;                /* 64 bytes */
+int tafl_gmcts_begin(tafl_batch* b, uint32_t max_sims, uint32_t edges_per_node);
+int tafl_gmcts_step(tafl_batch* b, const float* priors, const float* values, int in_is_device, double c_puct, uint32_t n_sims,
+                    uint32_t* out_waiting);
+int tafl_gmcts_leaves(tafl_batch* b, uint8_t* boards, uint8_t* sides, uint8_t* waiting, int out_is_device);
+int tafl_gmcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_children, uint32_t* out_n);
+int tafl_gmcts_root_visits(tafl_batch* b, uint32_t* out, int out_is_device);
+int tafl_gmcts_policy(tafl_batch* b, double temp, double* out, int out_is_device);
+int tafl_gmcts_get_stats(tafl_batch* b, tafl_gmcts_stats* out);
+
 /* ---- replay buffer on disk: write_to_file, game/main.rs:86-132 ------------------------
  * Host-only, byte-exact text format of the reference: per record `side_len` lines of comma-separated matrix values, one line
  * with the comma-separated vector, one line value1, one line value2; every line ends in '\n'.

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "../../alphazeroforhnefatafl_amd/csrc/tafl_ops.hpp"
+#include "../../alphazeroforhnefatafl_amd/csrc/tafl_guided.hpp"
 
 using namespace tafl;
 
@@ -107,6 +108,60 @@ struct Host {
     }
 };
 
+// guided MCTS session on host memory: the same Guided<NL,W>::step the k_gmcts_step kernel runs, one game after the other
+struct GSessionBase {
+    virtual ~GSessionBase() {}
+    virtual uint32_t step(const float* priors, const float* values, double c_puct, uint32_t n_sims) = 0;
+    virtual void leaves(uint8_t* boards, uint8_t* sides, uint8_t* waiting) = 0;
+    virtual void root_children(tafl_root_child* out, uint32_t max_children, uint32_t* out_n) = 0;
+    uint64_t sims = 0, predicts = 0, terminal_hits = 0, faults = 0;
+};
+template <int NL, int W>
+struct GSession : GSessionBase {
+    using GD = Guided<NL, W>;
+    using IO = StateIO<NL>;
+    Consts<NL> C; GuidedMem M; uint32_t A, n;
+    std::vector<Quad> ns; std::vector<GNode> hdr; std::vector<uint32_t> pedge, ntop, etop, leaf, simsd; std::vector<GEdge> edges; std::vector<uint8_t> kind, fault;
+    int init(const tafl_rules* r, uint8_t side, const tafl_state* st, uint32_t G, uint32_t max_sims, uint32_t edges_per_node) {
+        if (make_consts<NL, W>(*r, side, C)) return -1;
+        n = side; A = (uint32_t)side * side * 2u * (side - 1u);
+        M.G = G; M.node_cap = max_sims + 1; M.edge_cap = (max_sims + 1) * edges_per_node;
+        ns.resize((size_t)M.node_cap * G * IO::QUADS); hdr.resize((size_t)M.node_cap * G); pedge.resize((size_t)M.node_cap * G); edges.resize((size_t)M.edge_cap * G);
+        ntop.resize(G); etop.resize(G); leaf.resize(G); simsd.resize(G); kind.resize(G); fault.resize(G);
+        M.node_state = ns.data(); M.hdr = hdr.data(); M.pedge = pedge.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
+        M.leaf = leaf.data(); M.kind = kind.data(); M.fault = fault.data(); M.sims_done = simsd.data();
+        for (uint32_t g = 0; g < G; ++g) { DState<NL> s; state_from_abi<NL>(st[g], s); GD::init_game(M, g, s); }
+        return 0;
+    }
+    uint32_t step(const float* priors, const float* values, double c_puct, uint32_t n_sims) override {
+        uint32_t waiting = 0;
+        for (uint32_t g = 0; g < M.G; ++g) {
+            GuidedStats gs; memset(&gs, 0, sizeof gs);
+            GD::step(M, g, priors ? priors + (size_t)g * A : nullptr, values ? values[g] : 0.f, A, c_puct, n_sims, C, gs);
+            sims += gs.sims; predicts += gs.predicts; terminal_hits += gs.terminal_hits; faults += gs.faults;
+            waiting += M.kind[g] == 1;
+        }
+        return waiting;
+    }
+    void leaves(uint8_t* boards, uint8_t* sides, uint8_t* waiting) override {
+        for (uint32_t g = 0; g < M.G; ++g) {
+            const bool w = M.kind[g] == 1; const uint32_t L = w ? M.leaf[g] : 0u;
+            DState<NL> s; IO::load_rec(M.node_state + ((size_t)L * M.G + g) * IO::QUADS, s);
+            for (uint32_t r = 0; r < n; ++r) for (uint32_t c = 0; c < n; ++c) {
+                const uint32_t bit = r * (uint32_t)W + c; uint32_t v = 0;
+                if ((r == 0 || r == n - 1u) && (c == 0 || c == n - 1u)) v = 20;
+                if (r == n / 2u && c == n / 2u) v = 30;
+                if (test(s.def, bit)) v += (r == TAFL_F_KROW(s.flags) && c == TAFL_F_KCOL(s.flags)) ? 5u : 1u; else if (test(s.att, bit)) v += 1u;
+                boards[((size_t)g * n + r) * n + c] = (uint8_t)v;
+            }
+            sides[g] = (uint8_t)((s.flags & TAFL_F_SIDE) ? TAFL_DEFENDER : TAFL_ATTACKER); waiting[g] = w ? 1 : 0;
+        }
+    }
+    void root_children(tafl_root_child* out, uint32_t max_children, uint32_t* out_n) override {
+        for (uint32_t g = 0; g < M.G; ++g) out_n[g] = GD::root_children(M, g, out + (size_t)g * max_children, max_children);
+    }
+};
+
 #define DISPATCH(call)                                              \
     switch (word_bits) {                                            \
         case 64:  return Host<2, 7>::call;                          \
@@ -116,6 +171,19 @@ struct Host {
     }
 
 extern "C" {
+void* hs_gmcts_new(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t G, uint32_t max_sims, uint32_t edges_per_node) {
+    GSessionBase* s = nullptr; int rc = -2;
+    if (word_bits == 64) { auto* x = new GSession<2, 7>(); rc = x->init(r, n, st, G, max_sims, edges_per_node); s = x; }
+    else if (word_bits == 128) { auto* x = new GSession<4, 11>(); rc = x->init(r, n, st, G, max_sims, edges_per_node); s = x; }
+    else if (word_bits == 256) { auto* x = new GSession<8, 15>(); rc = x->init(r, n, st, G, max_sims, edges_per_node); s = x; }
+    if (rc) { delete s; return nullptr; }
+    return s;
+}
+void hs_gmcts_free(void* h) { delete (GSessionBase*)h; }
+uint32_t hs_gmcts_step(void* h, const float* priors, const float* values, double c_puct, uint32_t n_sims) { return ((GSessionBase*)h)->step(priors, values, c_puct, n_sims); }
+void hs_gmcts_leaves(void* h, uint8_t* boards, uint8_t* sides, uint8_t* waiting) { ((GSessionBase*)h)->leaves(boards, sides, waiting); }
+void hs_gmcts_root_children(void* h, tafl_root_child* out, uint32_t max_children, uint32_t* out_n) { ((GSessionBase*)h)->root_children(out, max_children, out_n); }
+void hs_gmcts_counts(void* h, uint64_t* out4) { GSessionBase* s = (GSessionBase*)h; out4[0] = s->sims; out4[1] = s->predicts; out4[2] = s->terminal_hits; out4[3] = s->faults; }
 void hs_force_generic(int on) { g_force_generic = on != 0; }
 void hs_set_spec_k(uint32_t k) { g_spec_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
 void hs_set_spec_cooldown(uint32_t c) { g_spec_cooldown = c > 200 ? 200 : c; }

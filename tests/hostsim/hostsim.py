@@ -32,6 +32,19 @@ def lib():
         sig("hs_rollout", P(TaflState), u32, u64, u32, u32, u64, P(TaflRolloutResult))
         sig("hs_random_advance", P(TaflState), u32, u64, P(u32), u64)
         sig("hs_mcts", P(TaflState), u32, P(TaflMctsParams), u64, P(TaflRootChild), u32, P(u32), P(TaflMctsStats))
+        vp = C.c_void_p
+        L.hs_gmcts_new.restype = vp
+        L.hs_gmcts_new.argtypes = head + [P(TaflState), u32, u32, u32]
+        L.hs_gmcts_free.restype = None
+        L.hs_gmcts_free.argtypes = [vp]
+        L.hs_gmcts_step.restype = u32
+        L.hs_gmcts_step.argtypes = [vp, P(C.c_float), P(C.c_float), C.c_double, u32]
+        L.hs_gmcts_leaves.restype = None
+        L.hs_gmcts_leaves.argtypes = [vp, P(u8), P(u8), P(u8)]
+        L.hs_gmcts_root_children.restype = None
+        L.hs_gmcts_root_children.argtypes = [vp, P(TaflRootChild), u32, P(u32)]
+        L.hs_gmcts_counts.restype = None
+        L.hs_gmcts_counts.argtypes = [vp, P(u64)]
         L.hs_set_spec_cooldown.restype = None
         L.hs_set_spec_cooldown.argtypes = [C.c_uint32]
         L.hs_set_spec_k.restype = None
