@@ -89,6 +89,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"(make -C alphazeroforhnefatafl_amd/csrc). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64, and if this library pulled
+        # in /opt/rocm's copies first a later `import torch` would find no GPU.  Loading torch first (when it is installed)
+        # makes both share torch's runtime; TAFLHIP_NO_TORCH_PRELOAD=1 skips this for torch-free processes.
+        if not os.environ.get("TAFLHIP_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             f = getattr(L, name)          # AttributeError if the symbol is not exported
