@@ -65,6 +65,12 @@ def main():
     for name, net in (("engine_only_constant_priors", Const()), ("torch_conv_fp16", Conv())):
         b = lg.new_batch(n, boards.COPENHAGEN)
         m = GuidedMCTS(b, net, MCTSArgs(numMCTSSims=args.sims, cpuct=1.0), edges_per_node=args.edges_per_node, device=True, buffers=bufs)
+        bt.zero_(); st.zero_(); wt.zero_()
+        for _ in range(3):
+            net.predict_batch()                                  # MIOpen / hipBLASLt kernel selection happens on the first calls
+        m.search_all()                                           # first search: allocates the arena (26 GB at the default size)
+        b.reset_fen(boards.COPENHAGEN, rules.COPENHAGEN.starting_side)
+        m.rounds = 0
         lg.sync(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         m.search_all()
