@@ -53,6 +53,13 @@ def cpu_baseline(n_sims, c_puct, seed, max_plies, budget_s=20.0):
     # ctypes releases the GIL inside the C call
     import threading
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                    # a container's CPU share (cgroup v2 quota) is what this process can really use
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            ncores = max(1, min(ncores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    ncores = min(ncores, 32)                # bounded sample: a GPU box hands one GPU's job a 16-CPU share
     mt_budget = budget_s / 2.0
     mt_sims = [0] * ncores
 
