@@ -100,12 +100,15 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_step(Consts<NL> C, Quad* soa, ui
 }
 
 template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_step_kth(Consts<NL> C, Quad* soa, uint32_t n, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff) {
+__global__ __launch_bounds__(TAFL_BLOCK) void k_step_kth(Consts<NL> C, Quad* soa, uint32_t n, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff, uint32_t mw) {
+    extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw]: each game's dense legal mask, private to its lane
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * mw; i += TAFL_BLOCK) lds_masks[i] = 0;
+    __syncthreads();
     if (g >= n) return;
     DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
     tafl_effects e; tafl_play p;
-    Ops<NL, W>::step_kth(st, ranks[g], C, &p, &e);
+    Ops<NL, W>::step_kth(st, ranks[g], C, &p, &e, lds_masks + (size_t)threadIdx.x * mw, mw);
     StateIO<NL>::store_soa(soa, n, g, st);
     if (eff) eff[g] = e;
     if (out_plays) out_plays[g] = p;
@@ -623,9 +626,9 @@ int tafl_step_kth(tafl_batch* b, const uint32_t* ranks, tafl_play* out_plays, ta
     HIPCHK(hipMemcpyAsync(b->ranks.p, ranks, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
     {
         SpanGuard sg(c, KC_STEP);
-        DISPATCH_NLW(c, hipLaunchKernelGGL((k_step_kth<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
-                                           (const uint32_t*)b->ranks.p, out_plays ? (tafl_play*)b->out_plays.p : nullptr,
-                                           out_effects ? (tafl_effects*)b->effects.p : nullptr));
+        DISPATCH_NLW(c, hipLaunchKernelGGL((k_step_kth<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), TAFL_BLOCK * tafl_action_mask_words(c) * sizeof(uint32_t), c->stream,
+                                           CC, b->soa, n, (const uint32_t*)b->ranks.p, out_plays ? (tafl_play*)b->out_plays.p : nullptr,
+                                           out_effects ? (tafl_effects*)b->effects.p : nullptr, tafl_action_mask_words(c)));
     }
     HIPCHK(hipGetLastError());
     if (out_plays) HIPCHK(hipMemcpyAsync(out_plays, b->out_plays.p, sizeof(tafl_play) * n, hipMemcpyDeviceToHost, c->stream));

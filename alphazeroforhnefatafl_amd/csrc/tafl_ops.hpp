@@ -171,28 +171,40 @@ struct Ops {
         status_to_effects(st, code, e);
         if (eff) *eff = e;
     }
-    // k-th legal play in canonical order; returns false if there is none
-    static TAFL_HD bool kth_canonical(const S& st, uint32_t k, const K& C, Move& out) {
-        Move cur = E::canon_start();
-        const uint32_t side = st.flags & TAFL_F_SIDE;
-        for (uint32_t i = 0; i <= k; ++i) if (!E::canon_next(st, side, C, cur)) return false;
-        out = cur; return true;
+    // inverse of action_of
+    static TAFL_HD Move move_of_action(uint32_t a, const K& C) {
+        const uint32_t nm = C.n - 1, per = 2u * nm;
+        const uint32_t tile = a / per, slot = a % per, r = tile / C.n, c = tile % C.n;
+        Move m; m.from = r * (uint32_t)W + c;
+        if (slot < nm - r) { m.dir = 0; m.dist = slot + 1; }
+        else if (slot < nm) { m.dir = 1; m.dist = slot - (nm - r) + 1; }
+        else if (slot < per - c) { m.dir = 2; m.dist = slot - nm + 1; }
+        else { m.dir = 3; m.dist = slot - (per - c) + 1; }
+        m.to = (uint32_t)((int)m.from + E::delta(m.dir) * (int)m.dist);
+        return m;
     }
-    static TAFL_HD void step_kth(S& st, uint32_t rank, const K& C, tafl_play* out_play, tafl_effects* eff) {
-        Moves<NL> mv; E::movegen(st, st.flags & TAFL_F_SIDE, C, mv);
+    // The (rank mod count)-th legal play in canonical order = the (rank mod count)-th set bit of the dense action mask (the
+    // action index preserves the canonical order).  `mask`: zeroed scratch of mask_words words (LDS on the device).
+    static TAFL_HD void step_kth(S& st, uint32_t rank, const K& C, tafl_play* out_play, tafl_effects* eff, uint32_t* mask, uint32_t mask_words) {
+        const uint32_t total = movegen(st, C, mask);
         tafl_effects e; caps_to_effects(bz<NL>(), 0, e);
         tafl_play pl; pl.from_row = pl.from_col = pl.axis = 0; pl.disp = 0;
         int code;
-        if (mv.total == 0) code = TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING ? TAFL_PLAY_GAME_OVER : TAFL_PLAY_NO_PIECE;
+        if (total == 0) code = TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING ? TAFL_PLAY_GAME_OVER : TAFL_PLAY_NO_PIECE;
         else {
-            Move m;
-            if (kth_canonical(st, rank % mv.total, C, m)) {
+            uint32_t k = rank % total, a = 0; bool found = false;
+            for (uint32_t w = 0; w < mask_words; ++w) {
+                const uint32_t v = mask[w], c = (uint32_t)__builtin_popcount(v);
+                if (!found) { if (k < c) { a = w * 32u + nth_set_bit32(v, k); found = true; } else k -= c; }
+            }
+            if (found) {
+                const Move m = move_of_action(a, C);
                 pl = to_play(m);
                 StepOut<NL> so; Moves<NL> nx;
                 E::apply(st, m, C, &so, nx);
                 caps_to_effects(so.captures, so.n_captures, e);
                 code = TAFL_PLAY_OK;
-            } else code = TAFL_PLAY_NO_PIECE;     // canonical and set-wise generators disagree: surfaced by the tests
+            } else code = TAFL_PLAY_NO_PIECE;     // count and mask disagree: surfaced by the tests
         }
         status_to_effects(st, code, e);
         if (eff) *eff = e;

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "../../alphazeroforhnefatafl_amd/csrc/tafl_ops.hpp"
 #include "../../alphazeroforhnefatafl_amd/csrc/tafl_guided.hpp"
@@ -46,7 +47,8 @@ struct Host {
     }
     static int step_kth(const tafl_rules* r, uint8_t n, tafl_state* st, uint32_t cnt, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff) {
         K C; if (consts(r, n, C)) return -1;
-        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::step_kth(s, ranks[g], C, out_plays ? &out_plays[g] : nullptr, eff ? &eff[g] : nullptr); state_to_abi<NL>(s, n, st[g]); }
+        const uint32_t mw = ((uint32_t)n * n * 2u * (n - 1u) + 31u) / 32u; std::vector<uint32_t> mask(mw);
+        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); std::fill(mask.begin(), mask.end(), 0u); O::step_kth(s, ranks[g], C, out_plays ? &out_plays[g] : nullptr, eff ? &eff[g] : nullptr, mask.data(), mw); state_to_abi<NL>(s, n, st[g]); }
         return 0;
     }
     static int side_can_play(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t cnt, uint8_t side, uint8_t* out) {

@@ -37,7 +37,9 @@ def main():
             states = b.download()
             scratch = logic.new_batch(G)
             scratch.upload(states)
+            logic.timing_reset()
             plays, _ = scratch.do_kth_play(ranks)
+            ms_k, k_k = logic.timing_get(KC_STEP)                # tafl_step_kth: legal mask in LDS, k-th set bit, do_valid_play
             scratch.close()
             logic.timing_reset()
             ms_s = k_s = 0
@@ -59,6 +61,7 @@ def main():
                    "movegen_counts_us": ms_c / k_c * 1e3, "movegen_counts_Mgames_s": G / (ms_c / k_c) / 1e3,
                    "movegen_masks_us": ms_m / k_m * 1e3, "movegen_masks_Mgames_s": G / (ms_m / k_m) / 1e3,
                    "movegen_masks_GBps": G * (sg + 4 + mask_b) / (ms_m / k_m) / 1e6,
+                   "step_kth_us": ms_k / k_k * 1e3,
                    "step_us": ms_s / k_s * 1e3, "step_Msteps_s": G / (ms_s / k_s) / 1e3,
                    "step_GBps": G * (2 * sg + 4 + 4 + 40) / (ms_s / k_s) / 1e6,
                    "rollout_ms": ms_r / k_r, "rollout_Gplies_s": plies_total / (ms_r / k_r) / 1e6}
