@@ -173,7 +173,8 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_init(Consts<NL> C, const Qu
 // tree phase of the simulation pipeline: consume finished playouts (backup), run as many further simulations as can be
 // served by ready slots, then issue the next slots (tafl_ops.hpp mcts_tree_step)
 template <int NL, int W, int PRESET>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, unsigned long long* stats) {
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, unsigned long long* stats,
+                                                          uint32_t* work, uint32_t* work_count) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     TAFL_PICK_CONSTS(C, Carg);
     LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
@@ -181,6 +182,19 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
     const bool live = g < M.G && (M.sim_next[g] < n_sims || M.kind[g] == 1);
     if (__ballot(live) == 0ull) return;                       // whole wave finished: nothing to do, nothing to count
     if (live) Ops<NL, W>::mcts_tree_step(M, g, c_puct, n_sims, C, ls);
+    // dense work list of the playouts this round has to run, (slot << 27 | game): the playout kernel then runs full waves only,
+    // however few games are still searching (one atomic per wave and slot)
+    for (uint32_t j = 0; j < M.spec_k; ++j) {
+        const bool need = live && j < M.spec_n[g] && M.spec_kind[(size_t)j * M.G + g] == 1;
+        const unsigned long long bal = __ballot(need);
+        if (bal == 0ull) continue;
+        const int leader = __ffsll((long long)bal) - 1;
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(work_count, (uint32_t)__popcll(bal));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (need) work[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (j << 27) | g;
+    }
     stat_add(stats, ST_SIMS, ls.sims); stat_add(stats, ST_DEPTH, ls.depth); stat_add(stats, ST_SCANNED, ls.scanned);
     stat_add(stats, ST_TERMINAL, ls.terminal_hits); stat_add(stats, ST_FAULTS, ls.faults);
     stat_add(stats, ST_ROLLOUTS, ls.rollouts); stat_add(stats, ST_PLIES, ls.rollout_plies);
@@ -188,19 +202,21 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
     for (uint32_t r = 0; r < 16; ++r) stat_add(stats, ST_REASON0 + r, (uint32_t)((ls.reason_hist4 >> (4u * r)) & 15ull));
 }
 
-// the dominant kernel: one seeded random playout per (slot, game), state resident in registers.  Slot-major grid: block b
-// serves slot b / blocks_per_slot, so spec_k slots per game put up to spec_k waves on every SIMD.
+// the dominant kernel: one seeded random playout per entry of the round's work list (slot, game), state resident in registers.
+// spec_k slots per game put up to spec_k waves on every SIMD.
 template <int NL, int W, int PRESET>
 __global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim_offset,
-                                                                       uint32_t max_plies, uint32_t blocks_per_slot, unsigned long long* stats) {
-    const uint32_t j = blockIdx.x / blocks_per_slot;
-    const uint32_t g = (blockIdx.x % blocks_per_slot) * TAFL_BLOCK + threadIdx.x;
+                                                                       uint32_t max_plies, const uint32_t* work, const uint32_t* work_count,
+                                                                       unsigned long long* stats) {
+    const uint32_t cnt = *work_count;
+    if (blockIdx.x * TAFL_BLOCK >= cnt) return;
+    const uint32_t i = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     TAFL_PICK_CONSTS(C, Carg);
-    const bool work = g < M.G && j < M.spec_n[g] && M.spec_kind[(size_t)j * M.G + g] == 1;
-    const unsigned long long wb = __ballot(work);
-    if (wb == 0ull) return;
-    if (work) Ops<NL, W>::mcts_slot_rollout(M, j, g, seed, base + g, sim_offset, max_plies, C);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&stats[ST_EXEC], (unsigned long long)__popcll(wb));
+    const bool has = i < cnt;
+    const uint32_t e = has ? work[i] : 0u;
+    const uint32_t j = e >> 27, g = e & 0x07FFFFFFu;
+    if (has) Ops<NL, W>::mcts_slot_rollout(M, j, g, seed, base + g, sim_offset, max_plies, C);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&stats[ST_EXEC], (unsigned long long)__popcll(__ballot(has)));
 }
 
 template <int NL, int W>
@@ -331,7 +347,7 @@ struct tafl_batch {
     MctsMem mem; bool has_mem; uint32_t reserved_sims;
     DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, rvalue, fault, stats, children, children_n, visits;
     DevBuf best_plays, best_visits, enc, policy;
-    DevBuf spec_cool;
+    DevBuf spec_cool, work, work_count;
     DevBuf sim_next, spec_state, spec_value, spec_kind, spec_reason, spec_plies, spec_parent, spec_o0, spec_first, spec_n;
     uint32_t spec_k, spec_cooldown;
     tafl_mcts_stats last_stats; bool ran;
@@ -492,7 +508,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->spec_cool,
+                      &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->spec_cool, &b->work, &b->work_count,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
                       &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
     for (DevBuf* d : bufs) d->release();
@@ -695,7 +711,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     const size_t k = b->spec_k;
     NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * quads_of(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n);
     NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_parent, n * 4); NEED(b->spec_o0, n * 4); NEED(b->spec_first, n * 4);
-    NEED(b->spec_n, n); NEED(b->spec_cool, n);
+    NEED(b->spec_n, n); NEED(b->spec_cool, n); NEED(b->work, k * n * 4); NEED(b->work_count, 4);
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
     b->mem.kind = (uint8_t*)b->kind.p; b->mem.rvalue = (int8_t*)b->rvalue.p; b->mem.fault = (uint8_t*)b->fault.p;
@@ -729,6 +745,7 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     // re-probed for 8 rounds every 64.  Results do not depend on any of this (tafl_ops.hpp mcts_tree_step).
     const uint32_t bps = grid_of(n);
     const uint32_t full_k = b->spec_k;
+    uint32_t* wlist = (uint32_t*)b->work.p; uint32_t* wcount = (uint32_t*)b->work_count.p;
     uint32_t k_now = full_k, rounds_in_mode = 0;
     unsigned long long last_issued = 0, last_hits = 0;
     double last_hit = 1.0;
@@ -740,16 +757,17 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
         const bool sample = full_k > 1 && ((k_now > 1 && (rounds_in_mode + 1) % 8 == 0) ||
                                            (k_now == 1 && (rounds_in_mode + 1 >= 64 || (round_ms[0] < 0 && rounds_in_mode + 1 == 4))));
         if (sample) HIPCHK(hipEventRecord(ev_a, c->stream));
+        HIPCHK(hipMemsetAsync(wcount, 0, sizeof(uint32_t), c->stream));
         {
             SpanGuard sg(c, KC_MCTS_TREE);
-            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, st));
+            DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, st, wlist, wcount));
         }
         {
             SpanGuard sg(c, KC_MCTS_ROLLOUT);
             // slots of the previous mode may still be pending in the first round after a switch: keep the grid at full_k then
             const uint32_t grid_k = (rounds_in_mode == 0) ? full_k : k_now;
             DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(bps * grid_k), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->seed,
-                                                  game_id_base, p->sim_offset, p->max_rollout_plies, bps, st));
+                                                  game_id_base, p->sim_offset, p->max_rollout_plies, wlist, wcount, st));
         }
         ++rounds_in_mode;
         if (sample) {
@@ -776,7 +794,8 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     M.spec_k = full_k;
     {
         SpanGuard sg(c, KC_MCTS_BACKUP);
-        DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, st));
+        HIPCHK(hipMemsetAsync(wcount, 0, sizeof(uint32_t), c->stream));
+        DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, st, wlist, wcount));
     }
     HIPCHK(hipGetLastError());
     b->ran = true;
