@@ -201,7 +201,7 @@ def main():
                          "algorithmic_bytes": alg_bytes_per_step, "kernel_ms": roll_s_per_step * 1e3, "per": "step (all k_mcts_rollout launches)",
                          "playouts_executed": executed,
                          "note": "register-resident playout: 68 algorithmic bytes per playout; the binding limit is integer VALU issue "
-                                 "(80 % of the measured 1-instruction-per-4-cycles-per-SIMD peak, profiles/r01_v7_fields), see DESIGN.md section 6"},
+                                 "(82 % of a 1-instruction-per-4-cycles-per-SIMD issue model, profiles/r01_v8_worklist; instruction-class rates in profiles/r01_valu_rates), see DESIGN.md section 6"},
         }
         if world == 1 and not args.no_cpu_baseline and args.board == "copenhagen11":
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpuct, args.seed, args.max_plies)
