@@ -219,6 +219,47 @@ __global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_m
     if ((threadIdx.x & 63) == 0) atomicAdd(&stats[ST_EXEC], (unsigned long long)__popcll(__ballot(has)));
 }
 
+// The fused form of the two kernels above: one wave owns 64 / K games for a whole chunk of rounds and alternates, without any
+// grid-wide synchronisation, between the tree phase (its games on the first 64 / K lanes) and the playout phase (K slots x 64 / K
+// games on all 64 lanes).  Nothing is shared between waves, so no wave ever waits for another: the tree phase of one wave hides
+// under the playouts of the other wave on its SIMD, the per-round launches disappear, and a wave leaves as soon as its own games
+// are done.  Same per-game functions, same memory layout, same results as the two-kernel path.
+template <int NL, int W, int PRESET, int K>
+__global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_mcts_fused(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, uint64_t seed,
+                                                                     uint64_t base, uint32_t sim_offset, uint32_t max_plies, uint32_t max_rounds,
+                                                                     unsigned long long* stats) {
+    constexpr uint32_t GPW = TAFL_BLOCK / K;                      // games per wave
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tg = blockIdx.x * GPW + lane;                  // tree phase: lane < GPW serves game tg
+    const uint32_t rj = lane / GPW, rg = blockIdx.x * GPW + (lane % GPW);   // playout phase: slot rj of game rg
+    TAFL_PICK_CONSTS(C, Carg);
+    LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
+    ls.reason_hist4 = 0; ls.spec_issued = ls.spec_hits = 0;
+    uint32_t executed = 0;
+    for (uint32_t round = 0; round < max_rounds; ++round) {
+        const bool live = lane < GPW && tg < M.G && (M.sim_next[tg] < n_sims || M.kind[tg] == 1);
+        if (__ballot(live) == 0ull) break;                        // every game of this wave has finished
+        if (live) Ops<NL, W>::mcts_tree_step(M, tg, c_puct, n_sims, C, ls);
+        if ((round & 3u) == 3u) {                                 // the packed 4-bit reason counters hold 15: at most 2 playouts are consumed per round
+            for (uint32_t r = 0; r < 16; ++r) stat_add(stats, ST_REASON0 + r, (uint32_t)((ls.reason_hist4 >> (4u * r)) & 15ull));
+            ls.reason_hist4 = 0;
+        }
+        __threadfence();                                          // slot records written by the tree lanes are read by all lanes
+        const bool work = rg < M.G && rj < M.spec_n[rg] && M.spec_kind[(size_t)rj * M.G + rg] == 1;
+        const unsigned long long wb = __ballot(work);
+        if (wb == 0ull) continue;
+        if (work) Ops<NL, W>::mcts_slot_rollout(M, rj, rg, seed, base + rg, sim_offset, max_plies, C);
+        executed += (uint32_t)__popcll(wb);
+        __threadfence();
+    }
+    stat_add(stats, ST_SIMS, ls.sims); stat_add(stats, ST_DEPTH, ls.depth); stat_add(stats, ST_SCANNED, ls.scanned);
+    stat_add(stats, ST_TERMINAL, ls.terminal_hits); stat_add(stats, ST_FAULTS, ls.faults);
+    stat_add(stats, ST_ROLLOUTS, ls.rollouts); stat_add(stats, ST_PLIES, ls.rollout_plies);
+    stat_add(stats, ST_SPEC_ISSUED, ls.spec_issued); stat_add(stats, ST_SPEC_HITS, ls.spec_hits);
+    for (uint32_t r = 0; r < 16; ++r) stat_add(stats, ST_REASON0 + r, (uint32_t)((ls.reason_hist4 >> (4u * r)) & 15ull));
+    if (lane == 0 && executed) atomicAdd(&stats[ST_EXEC], (unsigned long long)executed);
+}
+
 template <int NL, int W>
 __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_root_children(Consts<NL> C, MctsMem M, tafl_root_child* out, uint32_t max_children, uint32_t* out_n) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
@@ -349,7 +390,7 @@ struct tafl_batch {
     DevBuf best_plays, best_visits, enc, policy;
     DevBuf spec_cool, work, work_count;
     DevBuf sim_next, spec_state, spec_value, spec_kind, spec_reason, spec_plies, spec_parent, spec_o0, spec_first, spec_n;
-    uint32_t spec_k, spec_cooldown;
+    uint32_t spec_k, spec_cooldown; bool fused;
     tafl_mcts_stats last_stats; bool ran;
     // guided MCTS (external evaluator)
     GuidedMem gmem; bool g_has; uint32_t g_max_sims;
@@ -491,6 +532,7 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     if (!b) return fail(TAFL_ERR_OOM, "out of host memory");
     b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr; b->g_has = false; b->g_max_sims = 0;
     { const char* e = getenv("TAFL_SPEC_K"); int k = e ? atoi(e) : 2; b->spec_k = (uint32_t)(k < 1 ? 1 : (k > 8 ? 8 : k)); }
+    { const char* e = getenv("TAFL_MCTS_FUSED"); b->fused = !(e && atoi(e) == 0); }      // 0: the two-kernel pipeline (A/B measurements)
     { const char* e = getenv("TAFL_SPEC_COOLDOWN"); int v = e ? atoi(e) : 0; b->spec_cooldown = (uint32_t)(v < 0 ? 0 : (v > 200 ? 200 : v)); }
     memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats);
     const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
@@ -746,6 +788,55 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     const uint32_t bps = grid_of(n);
     const uint32_t full_k = b->spec_k;
     uint32_t* wlist = (uint32_t*)b->work.p; uint32_t* wcount = (uint32_t*)b->work_count.p;
+    if (b->fused && (full_k == 1 || full_k == 2)) {
+        // Fused path (k_mcts_fused): chunks of rounds per launch; between chunks the host reads the counters (one sync), stops when
+        // every game is done and applies the same cost model as below to keep or drop the second slot.
+        uint32_t k_now = full_k, chunks_in_mode = 0, rounds_left = p->n_sims + 1, chunk_len = 8;
+        unsigned long long last_issued = 0, last_hits = 0, last_sims = 0;
+        double last_hit = 1.0, sim_rate[2] = {-1.0, -1.0};          // simulations per ms without / with the second slot
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        HIPCHK(hipEventCreate(&ev_a)); HIPCHK(hipEventCreate(&ev_b));
+        int rcode = TAFL_OK;
+        while (rounds_left > 0) {
+            M.spec_k = k_now;
+            // a chunk ends in a grid-wide wait for the slowest wave: start with 8 rounds, double while the mode stays the same
+            const uint32_t chunk = (full_k == 1) ? rounds_left : ((k_now > 1 || sim_rate[0] < 0) ? chunk_len : 64u);
+            const uint32_t rounds = chunk < rounds_left ? chunk : rounds_left;
+            (void)hipEventRecord(ev_a, c->stream);
+            {
+                SpanGuard sg(c, KC_MCTS_ROLLOUT);
+                if (k_now == 2) { DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct,
+                                                                      p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st)); }
+                else { DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct,
+                                                           p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st)); }
+            }
+            (void)hipEventRecord(ev_b, c->stream);
+            rounds_left -= rounds; ++chunks_in_mode;
+            unsigned long long h[ST_COUNT];
+            if (hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rcode = fail(TAFL_ERR_HIP, "tafl_mcts_run: stats read-back failed"); break; }
+            if (h[ST_SIMS] >= (unsigned long long)n * p->n_sims) break;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev_a, ev_b) == hipSuccess && ms > 0.f) sim_rate[k_now > 1 ? 1 : 0] = (double)(h[ST_SIMS] - last_sims) / ms;
+            if (full_k > 1) {
+                if (k_now > 1) {
+                    const unsigned long long di = h[ST_SPEC_ISSUED] - last_issued, dh = h[ST_SPEC_HITS] - last_hits;
+                    last_hit = di > 0 ? (double)dh / (double)di : 1.0;
+                    // keep the second slot while it completes more simulations per ms than a plain round (measured when both are
+                    // known, else the 11x11 cost ratio 1.7 against 1 + hit rate)
+                    const bool worse = (sim_rate[0] > 0 && sim_rate[1] > 0) ? sim_rate[1] < sim_rate[0] * 1.02 : (1.0 + last_hit < 1.7 * 1.02);
+                    if (worse) { k_now = 1; chunks_in_mode = 0; chunk_len = 8; } else if (chunk_len < 16) chunk_len *= 2;
+                } else if (chunks_in_mode >= 1 && sim_rate[1] > 0 && sim_rate[0] > 0 && sim_rate[1] >= sim_rate[0] * 1.02) { k_now = full_k; chunks_in_mode = 0; chunk_len = 8; }
+                else if (chunks_in_mode >= 2 || sim_rate[1] < 0) { k_now = full_k; chunks_in_mode = 0; sim_rate[1] = -1.0; chunk_len = 8; }      // periodic re-probe
+            }
+            if (getenv("TAFL_DEBUG_MCTS")) fprintf(stderr, "[mcts] chunk rounds=%u ms=%.3f sims=%llu rate0=%.1f rate1=%.1f hit=%.3f -> k=%u\n", rounds, ms, (unsigned long long)(h[ST_SIMS] - last_sims), sim_rate[0], sim_rate[1], last_hit, k_now);
+            last_issued = h[ST_SPEC_ISSUED]; last_hits = h[ST_SPEC_HITS]; last_sims = h[ST_SIMS];
+        }
+        (void)hipEventDestroy(ev_a); (void)hipEventDestroy(ev_b);
+        if (rcode) return rcode;
+        HIPCHK(hipGetLastError());
+        b->ran = true;
+        return TAFL_OK;
+    }
     uint32_t k_now = full_k, rounds_in_mode = 0;
     unsigned long long last_issued = 0, last_hits = 0;
     double last_hit = 1.0;

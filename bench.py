@@ -166,13 +166,20 @@ def main():
         executed = int(stats.rollouts - stats.spec_hits + stats.spec_issued)
         roll_s_per_step = roll_ms * 1e-3 / args.steps
         sg_bytes = {7: 48, 11: 64, 13: 96}[side_]
-        alg_bytes_per_step = (sg_bytes + 4) * executed
-        achieved = alg_bytes_per_step / roll_s_per_step / 1e9 if roll_s_per_step > 0 else 0.0
         d_bar = stats.tree_depth_sum / max(stats.sims, 1)
         c_bar = stats.children_scanned / max(stats.tree_depth_sum, 1)
-        bytes_per_sim = d_bar * (64 + 16 * c_bar) + 32 + 2 * sg_bytes + 4        # SURVEY.md §8d formula
+        bytes_per_sim = d_bar * (64 + 16 * c_bar) + 32 + 2 * sg_bytes + 4        # SURVEY.md §8d formula (select + expand + rollout + backup)
+        # default path: ONE kernel (k_mcts_fused) runs tree phase and playouts, so its algorithmic bytes are the whole simulation's
+        # plus 68 B for every mispredicted speculative playout; TAFL_MCTS_FUSED=0 times k_mcts_rollout alone (68 B per playout)
+        fused = tree_n == 0
+        kname = "k_mcts_fused" if fused else "k_mcts_rollout"
+        if fused:
+            alg_bytes_per_step = bytes_per_sim * float(stats.sims) + (sg_bytes + 4) * max(0, executed - int(stats.rollouts))
+        else:
+            alg_bytes_per_step = (sg_bytes + 4) * executed
+        achieved = alg_bytes_per_step / roll_s_per_step / 1e9 if roll_s_per_step > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_k_mcts_rollout.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % kname)
         if os.path.exists(tpath) and G == GAMES_PER_GPU and args.board == "copenhagen11" and args.sims == 64:
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_step")        # rocprofv3 PMC passes of this same command (profiles/)
@@ -193,15 +200,16 @@ def main():
                      "reason_hist": [int(x) for x in stats.reason_hist],
                      "algorithmic_bytes_per_sim": bytes_per_sim,
                      "hbm_frac_sims": (total_sims / elapsed / world) * bytes_per_sim / (HBM_PEAK_GBS * 1e9)},
-            "kernels_ms": {"k_mcts_rollout": {"avg": roll_ms / max(roll_n, 1), "launches": int(roll_n), "total_per_step": roll_ms / args.steps},
+            "kernels_ms": {kname: {"avg": roll_ms / max(roll_n, 1), "launches": int(roll_n), "total_per_step": roll_ms / args.steps},
                            "k_mcts_tree": {"avg": tree_ms / max(tree_n, 1), "launches": int(tree_n), "total_per_step": tree_ms / args.steps},
                            "k_mcts_tree(final backup)": {"avg": bk_ms / max(bk_n, 1), "launches": int(bk_n)}},
-            "roofline": {"kernel": "k_mcts_rollout", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes_per_step, "kernel_ms": roll_s_per_step * 1e3, "per": "step (all k_mcts_rollout launches)",
-                         "playouts_executed": executed,
-                         "note": "register-resident playout: 68 algorithmic bytes per playout; the binding limit is integer VALU issue "
-                                 "(82 % of a 1-instruction-per-4-cycles-per-SIMD issue model, profiles/r01_v8_worklist; instruction-class rates in profiles/r01_valu_rates), see DESIGN.md section 6"},
+                         "algorithmic_bytes": alg_bytes_per_step, "kernel_ms": roll_s_per_step * 1e3, "per": "step (all %s launches)" % kname,
+                         "launch_avg_ms": roll_ms / max(roll_n, 1), "playouts_executed": executed,
+                         "note": "register-resident playouts (68 algorithmic bytes each) + the tree phase's node / edge records; the binding limit is integer "
+                                 "VALU issue (about 80 % of a 1-instruction-per-4-cycles-per-SIMD issue model; instruction-class rates in "
+                                 "profiles/r01_valu_rates), see DESIGN.md section 6"},
         }
         if world == 1 and not args.no_cpu_baseline and args.board == "copenhagen11":
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpuct, args.seed, args.max_plies)
