@@ -475,3 +475,28 @@ def test_training_tensor_writers():
     for g in range(G):
         vs = [kids[g * 256 + j].visits for j in range(cnt[g])]
         assert bv[g] == max(vs) and pu.play_tuple4(bp[g]) == pu.play_tuple4(kids[g * 256 + vs.index(max(vs))].play)
+
+
+@pytest.mark.parametrize("name,G,sims", [("copenhagen11", 200, 70), ("brandubh7", 130, 150), ("copenhagen13", 70, 40)])
+def test_fused_and_two_kernel_mcts_paths_agree(name, G, sims, monkeypatch):
+    """The default fused kernel (k_mcts_fused) and the two-kernel pipeline (TAFL_MCTS_FUSED=0: k_mcts_tree + k_mcts_rollout with the
+    dense work list) run the same per-game functions: identical root statistics and counters, for 1 and 2 playout slots per game.
+    The switches are read when a batch is created."""
+    rules, fen, wb, n, lg = _mk(name)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 3) % 50 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 19, plies, 5)
+    results = []
+    for fused, k in (("1", "2"), ("0", "2"), ("1", "1"), ("0", "1")):
+        monkeypatch.setenv("TAFL_MCTS_FUSED", fused)
+        monkeypatch.setenv("TAFL_SPEC_K", k)
+        b = gpu_batch(rules, n, wb, states, G)
+        b.mcts_run(sims, 1.0, 3, 300, game_id_base=5)
+        kids, cnt = b.mcts_root_children(256)
+        st = b.mcts_stats()
+        results.append(([(kids[g * 256 + j].action, kids[g * 256 + j].visits, float(kids[g * 256 + j].q).hex()) for g in range(G) for j in range(cnt[g])],
+                        list(cnt), (st.sims, st.rollouts, st.rollout_plies, st.tree_depth_sum, st.children_scanned, st.terminal_hits, st.faults),
+                        list(st.reason_hist)))
+        b.close()
+    for r in results[1:]:
+        assert r == results[0]
