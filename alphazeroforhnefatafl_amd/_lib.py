@@ -34,6 +34,7 @@ SYMBOLS = [
     ("tafl_batch_upload", _i32, [_vp, _P(TaflState), _u32, _u32]),
     ("tafl_batch_download", _i32, [_vp, _P(TaflState), _u32, _u32]),
     ("tafl_state_from_fen", _i32, [_vp, C.c_char_p, _u8, _P(TaflState)]),
+    ("tafl_state_to_fen", _i32, [_P(TaflState), _u32, C.c_char_p, _u32]),
     ("tafl_sync", _i32, [_vp]),
     ("tafl_movegen", _i32, [_vp, _P(_u32), _P(_u32)]),
     ("tafl_validate", _i32, [_vp, _P(TaflPlay), _P(_u8)]),

@@ -397,3 +397,13 @@ def action_decode(side_len: int, a: int) -> TaflPlay:
     if slot < m + (m - c):
         return TaflPlay(r, c, HORIZONTAL, slot - m + 1)
     return TaflPlay(r, c, HORIZONTAL, -(slot - m - (m - c) + 1))
+
+
+def state_to_fen(st: TaflState, word_bits: int) -> str:
+    """BoardState::to_fen (game/board/state.rs:271-295) through the library's host helper (no GPU needed)."""
+    from ._lib import check, lib
+    buf = C.create_string_buffer(1024)
+    n = lib().tafl_state_to_fen(C.byref(st), word_bits, buf, 1024)
+    if n < 0:
+        check(n)
+    return buf.value.decode()

@@ -525,6 +525,16 @@ int tafl_state_from_fen(const tafl_ctx* c, const char* fen, uint8_t side, tafl_s
     return TAFL_OK;
 }
 
+// BoardState::to_fen for one ABI state (host only).  Returns the length written (without the terminating NUL).
+int tafl_state_to_fen(const tafl_state* st, uint32_t word_bits, char* out, uint32_t cap) {
+    if (!st || !out || cap == 0) return fail(TAFL_ERR_INVALID_ARG, "tafl_state_to_fen: null argument");
+    std::string f;
+    if (state_to_fen(st, word_bits, &f)) return fail(TAFL_ERR_INVALID_ARG, "tafl_state_to_fen: bad word size / side length");
+    if (f.size() + 1 > cap) return fail(TAFL_ERR_CAPACITY, "tafl_state_to_fen: buffer too small");
+    memcpy(out, f.c_str(), f.size() + 1);
+    return (int)f.size();
+}
+
 int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     if (!c || !out || n == 0) return fail(TAFL_ERR_INVALID_ARG, "bad argument");
     HIPCHK(hipSetDevice(c->device));

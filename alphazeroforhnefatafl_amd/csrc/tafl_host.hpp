@@ -64,6 +64,30 @@ inline int fen_to_state(const char* fen, uint8_t side_to_play, uint32_t word_bit
     return 0;
 }
 
+// BoardState::to_fen (game/board/state.rs:271-295) from the ABI struct: 't' attacker, 'T' defender, 'K' the defender standing on the
+// king nibble's tile (get_piece, board/state.rs:173-187); runs of empty tiles as decimal numbers, rows joined by '/'.
+inline int state_to_fen(const tafl_state* st, uint32_t word_bits, std::string* out) {
+    int l64, rw;
+    if (word_params(word_bits, &l64, &rw) || st->side_len == 0 || st->side_len > rw) return -1;
+    const int top = l64 - 1;
+    const unsigned krow = (unsigned)(st->def[top] >> 60) & 15u, kcol = (unsigned)(st->att[top] >> 60) & 15u;
+    auto bit = [&](const uint64_t* w, unsigned idx) -> bool { return (w[idx / 64] >> (idx % 64)) & 1ull; };
+    out->clear();
+    for (unsigned r = 0; r < st->side_len; ++r) {
+        unsigned n_empty = 0;
+        for (unsigned c = 0; c < st->side_len; ++c) {
+            const unsigned idx = r * (unsigned)rw + c;
+            char ch = 0;
+            if (bit(st->def, idx)) ch = (r == krow && c == kcol) ? 'K' : 'T';
+            else if (bit(st->att, idx)) ch = 't';
+            if (ch) { if (n_empty) { *out += std::to_string(n_empty); n_empty = 0; } out->push_back(ch); } else ++n_empty;
+        }
+        if (n_empty) *out += std::to_string(n_empty);
+        if (r + 1 < st->side_len) out->push_back('/');
+    }
+    return 0;
+}
+
 // game/preset.rs:12-124
 inline int preset_rules(const char* name, tafl_rules* r) {
     memset(r, 0, sizeof *r);

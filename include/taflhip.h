@@ -254,6 +254,8 @@ int tafl_batch_reset_fen(tafl_batch* b, const char* fen, uint8_t side_to_play);
 int tafl_batch_upload(tafl_batch* b, const tafl_state* states, uint32_t first, uint32_t count);
 int tafl_batch_download(tafl_batch* b, tafl_state* states, uint32_t first, uint32_t count);
 int tafl_state_from_fen(const tafl_ctx* ctx, const char* fen, uint8_t side_to_play, tafl_state* out); /* host-only helper */
+/* BoardState::to_fen (game/board/state.rs:271-295) of one state; returns the string length or a negative error (host only) */
+int tafl_state_to_fen(const tafl_state* st, uint32_t word_bits, char* out, uint32_t cap);
 int tafl_sync(tafl_ctx* ctx);
 
 /* ---- hot path -----------------------------------------------------------------------------------

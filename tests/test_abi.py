@@ -85,3 +85,19 @@ def test_product_never_imports_oracle():
             else:
                 continue
             assert "liboracle" not in txt and "libhostsim" not in txt, path
+
+
+def test_state_to_fen_round_trips_against_the_oracle():
+    """tafl_state_to_fen (BoardState::to_fen, board/state.rs:271-295) vs the oracle's to_fen on start boards and random positions."""
+    import random
+    from alphazeroforhnefatafl_amd import abi
+    from oracle import oracle as orc
+    from tests import parity_util as pu
+    rng = random.Random(3)
+    for name, (rules, fen, wb) in pu.CONFIGS.items():
+        n = abi.fen_side_len(fen)
+        st = orc.GameState(fen, rules.starting_side, wb)
+        assert abi.state_to_fen(st.to_abi(), wb) == fen == st.to_fen(), name
+        states = pu.random_board_states(rng, n, wb, 40)
+        for g in range(40):
+            assert abi.state_to_fen(states[g], wb) == orc.GameState.from_abi(states[g], wb).to_fen(), (name, g)
