@@ -6,7 +6,7 @@ thousands of concurrent games) as hand-written HIP kernels behind a C-ABI (inclu
 from . import abi
 from .abi import Ruleset, boards, rules
 
-__all__ = ["abi", "Ruleset", "boards", "rules", "BatchedGameLogic", "GameBatch", "MCTS", "MCTSArgs", "GuidedMCTS"]
+__all__ = ["abi", "Ruleset", "boards", "rules", "BatchedGameLogic", "GameBatch", "MCTS", "MCTSArgs", "GuidedMCTS", "BatchedGame"]
 
 
 def __getattr__(name):
@@ -17,4 +17,7 @@ def __getattr__(name):
     if name in ("MCTS", "MCTSArgs", "GuidedMCTS"):
         from . import mcts
         return getattr(mcts, name)
+    if name == "BatchedGame":
+        from . import game
+        return game.BatchedGame
     raise AttributeError(name)

@@ -500,3 +500,36 @@ def test_fused_and_two_kernel_mcts_paths_agree(name, G, sims, monkeypatch):
         b.close()
     for r in results[1:]:
         assert r == results[0]
+
+
+def test_batched_game_history_and_undo():
+    """BatchedGame (game/game/mod.rs:75-116 for n games): random legal and illegal plays, undo, against the oracle's Game."""
+    from alphazeroforhnefatafl_amd import BatchedGame
+    rng = random.Random(9)
+    rules, fen, wb = pu.CONFIGS["brandubh7"]
+    G = 24
+    bg = BatchedGame(rules, fen, G)
+    og = [orc.Game(rules, fen, wb) for _ in range(G)]
+    olg = orc.GameLogic(rules, 7)
+    for step in range(30):
+        plays = (abi.TaflPlay * G)()
+        for g in range(G):
+            legal = olg.all_plays(og[g].state)
+            if legal and rng.random() < 0.8:
+                p = rng.choice(legal)
+            else:
+                p = pu.random_plays(rng, 7, 1)[0]
+            C.memmove(C.byref(plays[g]), C.byref(p), C.sizeof(abi.TaflPlay))
+        codes, _ = bg.do_play(plays)
+        for g in range(G):
+            code, _st = og[g].do_play(plays[g])
+            assert code == codes[g], (step, g)
+        if step % 4 == 3:
+            who = [g for g in range(G) if rng.random() < 0.5]
+            bg.undo_last_play(who)
+            for g in who:
+                og[g].undo_last_play()
+        cur = bg.state
+        for g in range(G):
+            assert bytes(cur[g]) == bytes(og[g].state.to_abi()), (step, g)
+            assert len(bg.play_history[g]) == len(og[g].play_history)
