@@ -50,6 +50,7 @@ SYMBOLS = [
     ("tafl_mcts_root_visits", _i32, [_vp, _P(_u32)]),
     ("tafl_mcts_policy", _i32, [_vp, _dbl, _P(_dbl)]),
     ("tafl_mcts_best_play", _i32, [_vp, _P(TaflPlay), _P(_u32)]),
+    ("tafl_mcts_play_best", _i32, [_vp, _P(TaflPlay), _P(TaflEffects)]),
     ("tafl_encode_boards", _i32, [_vp, _vp, _i32]),
     ("tafl_mcts_policy_device", _i32, [_vp, _dbl, _vp, _i32]),
     ("tafl_gmcts_begin", _i32, [_vp, _u32, _u32]),

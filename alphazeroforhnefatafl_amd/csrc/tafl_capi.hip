@@ -301,6 +301,37 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_best_play(Consts<NL> C, Mct
 
 // board_to_matrix (game/main.rs:55-83): corners 20, throne 30, soldier +1, king +5, one uint8 per tile, row-major n x n.
 // One lane per tile: consecutive lanes write consecutive bytes.
+// self-play step on the device: every game plays the most visited root play of its last search (first maximum, src/mcts.rs:216-227)
+// on its batch state (do_valid_play); games whose root has no visited child (finished games) stay as they are
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_play_best(Consts<NL> C, MctsMem M, Quad* soa, tafl_play* out_plays, tafl_effects* eff) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= M.G) return;
+    const NodeHdr h = M.hdr[g];
+    const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+    uint32_t best = 0; Move bm; bm.from = bm.to = bm.dir = bm.dist = 0;
+    for (uint32_t j = 0; j < h.m; ++j) {
+        const Edge e = eb[j];
+        if (e.n > best) { const NodeHdr ch = M.hdr[(size_t)e.child * M.G + g]; best = e.n; bm.from = ch.mv_from; bm.dir = ch.mv_dir; bm.dist = ch.mv_dist; }
+    }
+    DState<NL> st; StateIO<NL>::load_soa(soa, M.G, g, st);
+    tafl_effects e; Ops<NL, W>::caps_to_effects(bz<NL>(), 0, e);
+    tafl_play p; p.from_row = p.from_col = p.axis = 0; p.disp = 0;
+    int code = TAFL_PLAY_GAME_OVER;
+    if (best > 0 && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
+        bm.to = (uint32_t)((int)bm.from + Engine<NL, W>::delta(bm.dir) * (int)bm.dist);
+        p = Ops<NL, W>::to_play(bm);
+        StepOut<NL> so; Moves<NL> nx;
+        Engine<NL, W>::apply(st, bm, C, &so, nx);
+        Ops<NL, W>::caps_to_effects(so.captures, so.n_captures, e);
+        StateIO<NL>::store_soa(soa, M.G, g, st);
+        code = TAFL_PLAY_OK;
+    }
+    Ops<NL, W>::status_to_effects(st, code, e);
+    if (eff) eff[g] = e;
+    if (out_plays) out_plays[g] = p;
+}
+
 template <int NL, int W>
 __global__ __launch_bounds__(256) void k_encode_boards(Consts<NL> C, const Quad* soa, uint32_t n_games, uint8_t* out) {
     const uint32_t nn = C.n * C.n;
@@ -981,6 +1012,22 @@ int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visit
     HIPCHK(hipMemcpyAsync(out_plays, b->best_plays.p, sizeof(tafl_play) * n, hipMemcpyDeviceToHost, c->stream));
     if (out_visits) HIPCHK(hipMemcpyAsync(out_visits, b->best_visits.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return TAFL_OK;
+}
+
+int tafl_mcts_play_best(tafl_batch* b, tafl_play* out_plays, tafl_effects* out_effects) {
+    if (!b || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    if (out_plays) NEED(b->best_plays, sizeof(tafl_play) * n);
+    if (out_effects) NEED(b->effects, sizeof(tafl_effects) * n);
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_play_best<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, b->soa,
+                                       out_plays ? (tafl_play*)b->best_plays.p : nullptr, out_effects ? (tafl_effects*)b->effects.p : nullptr));
+    HIPCHK(hipGetLastError());
+    if (out_plays) HIPCHK(hipMemcpyAsync(out_plays, b->best_plays.p, sizeof(tafl_play) * n, hipMemcpyDeviceToHost, c->stream));
+    if (out_effects) HIPCHK(hipMemcpyAsync(out_effects, b->effects.p, sizeof(tafl_effects) * n, hipMemcpyDeviceToHost, c->stream));
+    if (out_plays || out_effects) HIPCHK(hipStreamSynchronize(c->stream));
+    b->ran = false;                                   // the tree belongs to the previous roots
     return TAFL_OK;
 }
 

@@ -255,6 +255,15 @@ class GameBatch:
         check(lib().tafl_gmcts_get_stats(self._h, C.byref(st)))
         return st
 
+    def mcts_play_best(self, want_results: bool = True):
+        """Every game plays the most visited root play of its last search, on the device (tafl_mcts_play_best)."""
+        if not want_results:
+            check(lib().tafl_mcts_play_best(self._h, None, None))
+            return None
+        plays, eff = (TaflPlay * self.n)(), (TaflEffects * self.n)()
+        check(lib().tafl_mcts_play_best(self._h, plays, eff))
+        return plays, eff
+
     def mcts_best_play(self):
         plays = (TaflPlay * self.n)()
         visits = (C.c_uint32 * self.n)()

@@ -305,6 +305,10 @@ int tafl_mcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_ch
 int tafl_mcts_root_visits(tafl_batch* b, uint32_t* out);
 int tafl_mcts_policy(tafl_batch* b, double temp, double* out);
 int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visits);
+/* self-play step without leaving the device: every game plays the most visited root play of its last tafl_mcts_run (first maximum)
+ * on its batch state (do_valid_play); finished games are left alone (effects.code = TAFL_PLAY_GAME_OVER).  out_* may be NULL
+ * (then nothing is copied back and the call only enqueues). */
+int tafl_mcts_play_best(tafl_batch* b, tafl_play* out_plays, tafl_effects* out_effects);
 
 /* ---- training-tensor writers (the step right after the hot path) ------------------------------
  * tafl_encode_boards: board_to_matrix (game/main.rs:55-83) for every game: uint8 [n * side_len * side_len], row-major;

@@ -533,3 +533,33 @@ def test_batched_game_history_and_undo():
         for g in range(G):
             assert bytes(cur[g]) == bytes(og[g].state.to_abi()), (step, g)
             assert len(bg.play_history[g]) == len(og[g].play_history)
+
+
+def test_mcts_play_best_is_best_play_plus_do_play():
+    """tafl_mcts_play_best (device-side self-play step) == tafl_mcts_best_play + tafl_step, and a short self-play loop stays
+    in step with the oracle driven by the same plays."""
+    rules, fen, wb, n, lg = _mk("brandubh7")
+    G = 96
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    a = gpu_batch(rules, n, wb, states, G)
+    ostates = pu.clone_states(states, G)
+    for move in range(12):
+        a.mcts_run(24, 1.0, 100 + move, 64, game_id_base=3)
+        want_plays, want_visits = a.mcts_best_play()
+        plays, eff = a.mcts_play_best()
+        live = [g for g in range(G) if want_visits[g] > 0]
+        for g in range(G):
+            if want_visits[g] > 0:
+                assert pu.play_tuple4(plays[g]) == pu.play_tuple4(want_plays[g]) and eff[g].code == 0
+            else:
+                assert eff[g].code != 0
+        sub = (abi.TaflPlay * G)()
+        for g in live:
+            C.memmove(C.byref(sub[g]), C.byref(want_plays[g]), C.sizeof(abi.TaflPlay))
+        oeff = orc.batch_step(lg, ostates, G, wb, sub)
+        cur = a.download()
+        for g in range(G):
+            if g in live:
+                assert pu.effects_tuple(oeff[g]) == pu.effects_tuple(eff[g]), (move, g)
+        # games without a play were not touched by the device; undo the oracle's rejected empty play bookkeeping (none: rejected plays change nothing)
+        assert pu.states_equal(cur, ostates, G), pu.first_state_diff(cur, ostates, G)
