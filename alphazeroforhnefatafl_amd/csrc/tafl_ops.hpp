@@ -289,10 +289,15 @@ struct Ops {
             const double sq = sqrt((double)h.ns);
             double cur_best = -__builtin_inf(); int best = -1;
             const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
-            for (uint32_t j = 0; j < h.m; ++j) {
-                const Edge e = eb[j];
-                const double u = e.q + cp * sq / (double)(1 + e.n);
-                if (u > cur_best) { cur_best = u; best = (int)j; }
+            // the edge records are fetched eight at a time (independent loads in flight: this loop is bound by memory latency),
+            // then evaluated in ascending order as mcts.py does
+            for (uint32_t j0 = 0; j0 < h.m; j0 += 8) {
+                Edge e[8];
+                TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) e[t] = eb[(j0 + t < h.m) ? j0 + t : j0];
+                TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) {
+                    const double u = e[t].q + cp * sq / (double)(1 + e[t].n);
+                    if (j0 + t < h.m && u > cur_best) { cur_best = u; best = (int)(j0 + t); }
+                }
             }
             ls.scanned += h.m;
             if (h.m < h.n_legal) {
