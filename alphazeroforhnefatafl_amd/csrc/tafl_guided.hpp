@@ -165,10 +165,14 @@ struct Guided {
                 GEdge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
                 const double sq = sqrt((double)h.ns), sq0 = sqrt((double)h.ns + TAFL_MCTS_EPS);
                 double cur_best = -__builtin_inf(); int best = -1;
-                for (uint32_t j = 0; j < h.n_legal; ++j) {
-                    const GEdge ed = eb[j];
-                    const double u = ed.n > 0 ? ed.q + c_puct * ed.p * sq / (double)(1 + ed.n) : c_puct * ed.p * sq0;
-                    if (u > cur_best) { cur_best = u; best = (int)j; }
+                // eight edge records in flight at a time (the scan is bound by memory latency), evaluated in ascending action order
+                for (uint32_t j0 = 0; j0 < h.n_legal; j0 += 8) {
+                    double ep[8], eq[8]; uint32_t en[8];
+                    TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) { const GEdge* e = &eb[(j0 + t < h.n_legal) ? j0 + t : j0]; ep[t] = e->p; eq[t] = e->q; en[t] = e->n; }
+                    TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) {
+                        const double u = en[t] > 0 ? eq[t] + c_puct * ep[t] * sq / (double)(1 + en[t]) : c_puct * ep[t] * sq0;
+                        if (j0 + t < h.n_legal && u > cur_best) { cur_best = u; best = (int)(j0 + t); }
+                    }
                 }
                 if (best < 0) { M.fault[g] = 1; gs.faults += 1; M.sims_done[g] = sims; return; }
                 uint32_t child = eb[best].child;
