@@ -420,7 +420,7 @@ struct tafl_batch {
     DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, rvalue, fault, stats, children, children_n, visits;
     DevBuf best_plays, best_visits, enc, policy;
     DevBuf spec_cool, work, work_count;
-    DevBuf sim_next, spec_state, spec_value, spec_kind, spec_reason, spec_plies, spec_parent, spec_o0, spec_first, spec_n;
+    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_parent, spec_o0, spec_first, spec_n;
     uint32_t spec_k, spec_cooldown; bool fused;
     tafl_mcts_stats last_stats; bool ran;
     // guided MCTS (external evaluator)
@@ -590,7 +590,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     if (b->soa) (void)hipFree(b->soa);
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
-                      &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_value, &b->spec_kind, &b->spec_reason,
+                      &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_meta, &b->spec_value, &b->spec_kind, &b->spec_reason,
                       &b->spec_plies, &b->spec_parent, &b->spec_o0, &b->spec_first, &b->spec_n, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->spec_cool, &b->work, &b->work_count,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
                       &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
@@ -792,13 +792,13 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->kind, n); NEED(b->rvalue, n); NEED(b->fault, n);
     NEED(b->stats, sizeof(unsigned long long) * ST_COUNT);
     const size_t k = b->spec_k;
-    NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * quads_of(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n);
+    NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * quads_of(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
     NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_parent, n * 4); NEED(b->spec_o0, n * 4); NEED(b->spec_first, n * 4);
     NEED(b->spec_n, n); NEED(b->spec_cool, n); NEED(b->work, k * n * 4); NEED(b->work_count, 4);
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
     b->mem.kind = (uint8_t*)b->kind.p; b->mem.rvalue = (int8_t*)b->rvalue.p; b->mem.fault = (uint8_t*)b->fault.p;
-    b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p;
+    b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p; b->mem.spec_meta = (uint32_t*)b->spec_meta.p;
     b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
     b->mem.spec_parent = (uint32_t*)b->spec_parent.p; b->mem.spec_o0 = (int32_t*)b->spec_o0.p; b->mem.spec_first = (uint32_t*)b->spec_first.p;
     b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_cool = (uint8_t*)b->spec_cool.p; b->mem.spec_k = b->spec_k; b->mem.spec_cooldown = b->spec_cooldown;

@@ -84,6 +84,8 @@ struct MctsMem {
     int8_t* spec_value;          // [j * G + g] playout value of slot j
     uint8_t* spec_kind;          // [j * G + g] 0 unused, 1 playout requested, 2 value ready, 3 no playout needed (terminal child)
     uint8_t* spec_reason;        // [j * G + g] playout termination reason
+    uint32_t* spec_meta;         // [j * G + g] slot j > 0: the play that leads to its leaf and the leaf's legal-play count:
+                                 //     from | dir << 8 | dist << 10 | n_legal << 16 (lets the real expansion of that child reuse the state)
     uint32_t* spec_plies;        // [j * G + g] plies of the playout
     uint32_t* spec_parent;       // [G] slot j is child (spec_o0 + j) of this node ...
     int32_t* spec_o0;            // [G] ... -1: slot 0 is the (unexpanded) root itself
@@ -307,11 +309,23 @@ struct Ops {
             if (best < 0) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
             if ((uint32_t)best < h.m) { cur = eb[best].child; continue; }
             // ---- expand edge h.m: getNextState (mcts.py:122-123) -------------------------------------------
-            S st; IO::load_rec(M.node_state + ((size_t)cur * M.G + g) * IO::QUADS, st);
-            Move mv; mv.from = h.cur_from; mv.to = 0; mv.dir = h.cur_dir; mv.dist = h.cur_dist;
-            if (!E::canon_next(st, st.flags & TAFL_F_SIDE, C, mv)) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
-            Moves<NL> nx;
-            E::apply(st, mv, C, nullptr, nx);
+            // If this child was prepared as a speculative slot of the previous issue (same parent, same ordinal), its state, play and
+            // legal-play count are already there: no second canon_next / apply.
+            S st; Move mv; Moves<NL> nx;
+            const int32_t sj = (int32_t)h.m - M.spec_o0[g];
+            const bool prepared = M.spec_n[g] > 1 && M.spec_parent[g] == cur && sj >= 1 && (uint32_t)sj < (uint32_t)M.spec_n[g]
+                                  && M.spec_kind[(size_t)(sj > 0 ? sj : 0) * M.G + g] >= 2;
+            if (prepared) {
+                const size_t so = (size_t)sj * M.G + g;
+                IO::load_rec(M.spec_state + so * IO::QUADS, st);
+                const uint32_t meta = M.spec_meta[so];
+                mv.from = meta & 0xFFu; mv.dir = (meta >> 8) & 3u; mv.dist = (meta >> 10) & 0x3Fu; mv.to = 0; nx.total = meta >> 16;
+            } else {
+                IO::load_rec(M.node_state + ((size_t)cur * M.G + g) * IO::QUADS, st);
+                mv.from = h.cur_from; mv.to = 0; mv.dir = h.cur_dir; mv.dist = h.cur_dist;
+                if (!E::canon_next(st, st.flags & TAFL_F_SIDE, C, mv)) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
+                E::apply(st, mv, C, nullptr, nx);
+            }
             const uint32_t id = M.node_top[g];
             uint32_t base = h.edge_base; uint32_t cap = h.cap;
             if (h.m == cap) {                                      // grow the edge array (amortised doubling)
@@ -397,6 +411,7 @@ struct Ops {
                     E::apply(cst, cur, C, nullptr, nx);
                     const bool term = TAFL_F_STATUS(cst.flags) != TAFL_STATUS_ONGOING;
                     IO::store_rec(M.spec_state + ((size_t)t * M.G + g) * IO::QUADS, cst);
+                    M.spec_meta[(size_t)t * M.G + g] = cur.from | (cur.dir << 8) | (cur.dist << 10) | (nx.total << 16);
                     M.spec_kind[(size_t)t * M.G + g] = term ? 3 : 1;
                     if (!term) ls.spec_issued += 1;
                     cnt = t + 1;

@@ -74,13 +74,13 @@ struct Host {
         std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS), sst((size_t)M.spec_k * G * IO::QUADS);
         std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
         std::vector<Edge> edges((size_t)M.edge_cap * G);
-        std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sparent(G), sfirst(G), splies((size_t)M.spec_k * G);
+        std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sparent(G), sfirst(G), splies((size_t)M.spec_k * G), smeta((size_t)M.spec_k * G);
         std::vector<int32_t> so0(G);
         std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), scool(G);
         std::vector<int8_t> rv(G), sval((size_t)M.spec_k * G);
         M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
         M.leaf = leaf.data(); M.kind = kind.data(); M.rvalue = rv.data(); M.fault = fault.data();
-        M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data();
+        M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data(); M.spec_meta = smeta.data();
         M.spec_plies = splies.data(); M.spec_parent = sparent.data(); M.spec_o0 = so0.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_cool = scool.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; state_from_abi<NL>(st[g], s); O::mcts_init_game(M, g, s, C); }
