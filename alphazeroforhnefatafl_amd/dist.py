@@ -50,3 +50,15 @@ def sum_over_ranks(value: float, world: int, device: str = "cpu") -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(value: float, world: int, device: str = "cpu"):
+    """Every rank's value, in rank order (per-GPU rates beside the max-time aggregate)."""
+    if world <= 1:
+        return [value]
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
