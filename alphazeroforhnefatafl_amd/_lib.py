@@ -63,6 +63,7 @@ SYMBOLS = [
     ("tafl_replay_append", _i32, [C.c_char_p, _P(_u8), _u8, _P(_u8), _u32, _u8, _u8, _u64]),
     ("tafl_replay_append_batch", _i32, [C.c_char_p, _P(_u8), _u8, _u32, _P(_u8), _P(_u32), _P(_u8), _P(_u8), _u64]),
     ("tafl_replay_read", _i32, [C.c_char_p, _u8, _u32, _P(_u8), _P(_u8), _u32, _P(_u32), _P(_u8), _P(_u8), _P(_u32)]),
+    ("tafl_mcts_round_trace", _i32, [_vp, _P(_u32), _P(_u32), _u32, _P(_u32)]),
     ("tafl_timing_enable", _i32, [_vp, _i32]),
     ("tafl_timing_reset", _i32, [_vp]),
     ("tafl_timing_get", _i32, [_vp, _i32, _P(_dbl), _P(_u64)]),

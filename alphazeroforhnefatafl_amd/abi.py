@@ -53,6 +53,14 @@ ROLLOUT_REASON_STUCK = 15
 
 MAX_LIMBS = 4
 
+# tafl_mcts_params.flags (include/taflhip.h): tuning fields choose how a search is executed, never what it returns
+MCTS_PIPELINE_DEFAULT, MCTS_PIPELINE_FUSED, MCTS_PIPELINE_TWO_KERNEL = 0, 1, 2
+
+
+def mcts_tune(pipeline: int = 0, slots: int = 0, parts: int = 0) -> int:
+    """TAFL_MCTS_TUNE_PIPELINE(pipeline) | TAFL_MCTS_TUNE_SLOTS(slots) | TAFL_MCTS_TUNE_PARTS(parts)."""
+    return ((pipeline & 15) << 4) | ((slots & 15) << 8) | ((parts & 15) << 12)
+
 
 def ps_none() -> int:
     return 0x0000

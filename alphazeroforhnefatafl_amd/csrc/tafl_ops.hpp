@@ -68,6 +68,11 @@ struct NodeHdr {                 // 32 bytes
 };
 struct Edge { double q; uint32_t n; uint32_t child; };   // Qsa, Nsa (mcts.py:20-21), next state     16 bytes
 
+// undo records of the speculation pass (mcts_speculate): the tree is modified in place by ASSUMED playout values to predict the next
+// selections and then restored bit for bit
+struct UndoE { uint32_t idx; uint32_t _pad; Edge e; };     // 24 bytes: edge index inside the game's arena + its old contents
+struct UndoH { uint32_t node; NodeHdr h; };                // 36 bytes
+
 struct MctsMem {
     Quad* node_state;            // [(k * G + g) * QUADS]
     NodeHdr* hdr;                // [k * G + g]
@@ -79,6 +84,8 @@ struct MctsMem {
     int8_t* rvalue;              // [G] playout value handed to the backup
     uint8_t* fault;              // [G]
     // ---- simulation pipeline (DESIGN.md "speculative playout slots") ------------------------------------------
+    // Slot j of game g is the playout keyed by simulation index spec_first[g] + j.  Slot 0 is the leaf of the pending real
+    // simulation; slots 1.. are PREDICTED expansions: child `spec_ord` of node `spec_node`.
     uint32_t* sim_next;          // [G] simulations completed so far
     Quad* spec_state;            // [(j * G + g) * QUADS] leaf state of slot j
     int8_t* spec_value;          // [j * G + g] playout value of slot j
@@ -87,13 +94,16 @@ struct MctsMem {
     uint32_t* spec_meta;         // [j * G + g] slot j > 0: the play that leads to its leaf and the leaf's legal-play count:
                                  //     from | dir << 8 | dist << 10 | n_legal << 16 (lets the real expansion of that child reuse the state)
     uint32_t* spec_plies;        // [j * G + g] plies of the playout
-    uint32_t* spec_parent;       // [G] slot j is child (spec_o0 + j) of this node ...
-    int32_t* spec_o0;            // [G] ... -1: slot 0 is the (unexpanded) root itself
+    uint32_t* spec_node;         // [j * G + g] slot j > 0 is child number spec_ord ...
+    uint32_t* spec_ord;          // [j * G + g] ... of this node (the child's index in the node's edge list when it is really expanded)
     uint32_t* spec_first;        // [G] simulation index of slot 0
-    uint8_t* spec_n;             // [G] slots issued
-    uint8_t* spec_cool;          // [G] speculation is skipped while > 0 (set after a misprediction: phases of the search in which a
-                                 //     visited child beats the unvisited ones make the prediction fail repeatedly)
-    uint32_t G, node_cap, edge_cap, spec_k, spec_cooldown;
+    uint8_t* spec_n;             // [G] slots issued (placeholders of predicted terminal revisits included)
+    uint8_t* spec_prio;          // [j * G + g] priority class of slot j in the round's work lists (0 first)
+    uint8_t* spec_w;             // [G] speculative slots this game may issue next (grows by one per fully consumed issue, shrinks to
+                                 //     what was consumed + 1 after a misprediction)
+    UndoE* ulog_e;               // [g * ulog_cap + i]
+    UndoH* ulog_h;               // [g * ulog_cap + i]
+    uint32_t G, node_cap, edge_cap, spec_k, ulog_cap;      // spec_k: slots per game that exist (capacity of the arrays above)
 };
 
 struct LaneStats {
@@ -245,8 +255,14 @@ struct Ops {
         M.hdr[g] = h;
         IO::store_rec(M.node_state + (size_t)g * IO::QUADS, root);
         M.node_top[g] = 1; M.edge_top[g] = 0; M.leaf[g] = 0; M.kind[g] = 0; M.rvalue[g] = 0; M.fault[g] = 0;
-        M.sim_next[g] = 0; M.spec_cool[g] = 0; M.spec_n[g] = 0; M.spec_parent[g] = 0; M.spec_o0[g] = 0; M.spec_first[g] = 0;
+        M.sim_next[g] = 0; M.spec_n[g] = 0; M.spec_first[g] = 0; M.spec_w[g] = (uint8_t)(M.spec_k > 0 ? M.spec_k - 1 : 0);
         for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;
+    }
+
+    // Q / N update of one edge with the value v seen from the edge's owner (mcts.py:127-133)
+    static TAFL_HD void edge_update(Edge* e, double v) {
+        if (e->n > 0) { e->q = ((double)e->n * e->q + v) / (double)(e->n + 1); e->n += 1; }   // mcts.py:127-129
+        else { e->q = v; e->n = 1; }                                                            // mcts.py:131-133
     }
 
     // backup of the pending simulation (mcts.py:127-136 unwound iteratively)
@@ -265,9 +281,7 @@ struct Ops {
         while (cur != 0) {
             const NodeHdr ch = M.hdr[(size_t)cur * M.G + g];
             NodeHdr* ph = &M.hdr[(size_t)ch.parent * M.G + g];
-            Edge* e = &M.edges[(size_t)g * M.edge_cap + ph->edge_base + ch.pslot];
-            if (e->n > 0) { e->q = ((double)e->n * e->q + v) / (double)(e->n + 1); e->n += 1; }   // mcts.py:127-129
-            else { e->q = v; e->n = 1; }                                                            // mcts.py:131-133
+            edge_update(&M.edges[(size_t)g * M.edge_cap + ph->edge_base + ch.pslot], v);
             ph->ns += 1;                                                                            // mcts.py:135
             v = -v;                                                                                 // mcts.py:136
             cur = ch.parent;
@@ -275,8 +289,33 @@ struct Ops {
         M.kind[g] = 0;
     }
 
-    // select + expand of one simulation (mcts.py:77-123).  Leaves M.leaf/M.kind set for the rollout + backup.
-    static TAFL_HD void mcts_select_expand(const MctsMem& M, uint32_t g, double c_puct, const K& C, LaneStats& ls) {
+    // the action with the highest upper confidence bound (mcts.py:104-119) among the visited children (a prefix of the canonical
+    // legal list) and the next unvisited one: returns its index in [0, h.m] (h.m = expand the next unvisited child), -1 if none.
+    static TAFL_HD int puct_pick(const MctsMem& M, uint32_t g, const NodeHdr& h, double c_puct) {
+        const double p = 1.0 / (double)h.n_legal;
+        const double cp = c_puct * p;
+        const double sq = sqrt((double)h.ns);
+        double cur_best = -__builtin_inf(); int best = -1;
+        const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+        // the edge records are fetched eight at a time (independent loads in flight: this loop is bound by memory latency),
+        // then evaluated in ascending order as mcts.py does
+        for (uint32_t j0 = 0; j0 < h.m; j0 += 8) {
+            Edge e[8];
+            TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) e[t] = eb[(j0 + t < h.m) ? j0 + t : j0];
+            TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) {
+                const double u = e[t].q + cp * sq / (double)(1 + e[t].n);
+                if (j0 + t < h.m && u > cur_best) { cur_best = u; best = (int)(j0 + t); }
+            }
+        }
+        if (h.m < h.n_legal) {
+            const double u0 = cp * sqrt((double)h.ns + TAFL_MCTS_EPS);
+            if (u0 > cur_best) { cur_best = u0; best = (int)h.m; }
+        }
+        return best;
+    }
+
+    // select + expand of simulation number `sim` (mcts.py:77-123).  Leaves M.leaf/M.kind set for the rollout + backup.
+    static TAFL_HD void mcts_select_expand(const MctsMem& M, uint32_t g, uint32_t sim, double c_puct, const K& C, LaneStats& ls) {
         uint32_t cur = 0;
         ls.sims += 1;
         for (uint32_t depth = 0; depth < M.node_cap + 1; ++depth) {
@@ -284,39 +323,20 @@ struct Ops {
             const NodeHdr h = *hp;
             if (h.term) { M.leaf[g] = cur; M.kind[g] = 2; ls.terminal_hits += 1; return; }
             if (!h.expanded) { M.leaf[g] = cur; M.kind[g] = 1; return; }
-            // pick the action with the highest upper confidence bound (mcts.py:104-119)
             ls.depth += 1;
-            const double p = 1.0 / (double)h.n_legal;
-            const double cp = c_puct * p;
-            const double sq = sqrt((double)h.ns);
-            double cur_best = -__builtin_inf(); int best = -1;
-            const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
-            // the edge records are fetched eight at a time (independent loads in flight: this loop is bound by memory latency),
-            // then evaluated in ascending order as mcts.py does
-            for (uint32_t j0 = 0; j0 < h.m; j0 += 8) {
-                Edge e[8];
-                TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) e[t] = eb[(j0 + t < h.m) ? j0 + t : j0];
-                TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) {
-                    const double u = e[t].q + cp * sq / (double)(1 + e[t].n);
-                    if (j0 + t < h.m && u > cur_best) { cur_best = u; best = (int)(j0 + t); }
-                }
-            }
+            const int best = puct_pick(M, g, h, c_puct);
             ls.scanned += h.m;
-            if (h.m < h.n_legal) {
-                const double u0 = cp * sqrt((double)h.ns + TAFL_MCTS_EPS);
-                if (u0 > cur_best) { cur_best = u0; best = (int)h.m; }
-            }
+            const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
             if (best < 0) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
             if ((uint32_t)best < h.m) { cur = eb[best].child; continue; }
             // ---- expand edge h.m: getNextState (mcts.py:122-123) -------------------------------------------
-            // If this child was prepared as a speculative slot of the previous issue (same parent, same ordinal), its state, play and
+            // If the slot of this simulation index was prepared for exactly this child (same node, same ordinal), its state, play and
             // legal-play count are already there: no second canon_next / apply.
             S st; Move mv; Moves<NL> nx;
-            const int32_t sj = (int32_t)h.m - M.spec_o0[g];
-            const bool prepared = M.spec_n[g] > 1 && M.spec_parent[g] == cur && sj >= 1 && (uint32_t)sj < (uint32_t)M.spec_n[g]
-                                  && M.spec_kind[(size_t)(sj > 0 ? sj : 0) * M.G + g] >= 2;
+            const uint32_t sj = sim - M.spec_first[g];
+            const size_t so = (size_t)(sj < M.spec_k ? sj : 0) * M.G + g;
+            const bool prepared = sj >= 1 && sj < (uint32_t)M.spec_n[g] && M.spec_kind[so] >= 1 && M.spec_node[so] == cur && M.spec_ord[so] == h.m;
             if (prepared) {
-                const size_t so = (size_t)sj * M.G + g;
                 IO::load_rec(M.spec_state + so * IO::QUADS, st);
                 const uint32_t meta = M.spec_meta[so];
                 mv.from = meta & 0xFFu; mv.dir = (meta >> 8) & 3u; mv.dist = (meta >> 10) & 0x3Fu; mv.to = 0; nx.total = meta >> 16;
@@ -355,70 +375,193 @@ struct Ops {
     }
 
     // ---- simulation pipeline ----------------------------------------------------------------------------------------
-    // One call advances game g by as many simulations as it can without waiting for a playout.  Every simulation does its
-    // real selection on the committed tree (mcts_select_expand); when that expands child `ord` of node P, the value of its
-    // playout is taken from a slot only if the slot was issued for exactly (P, ord, this simulation index) — the leaf
-    // state and the RNG key (game, sim) are then identical, so the value is the one a fresh playout would return.
-    // When no slot matches, the leaf becomes slot 0 and the next spec_k-1 slots are filled with the children
-    // ord+1, ord+2, ... of P for the following simulation indices: unvisited edges tie in PUCT and the lowest index wins
-    // (mcts.py:117-119), so unless a backed-up value lifts a visited child above them these are the next expansions.
+    // Simulations of one game are sequential; the pipeline runs the playouts of several FUTURE simulations of a game beside the
+    // pending one.  When simulation s has to wait for its playout (slot 0 = its leaf), mcts_speculate predicts the expansions of
+    // simulations s+1, s+2, ...: it assumes a value for every playout in flight, backs it up IN PLACE (undo log), runs the same
+    // PUCT selection the real simulation will run, notes which child of which node that selection expands (slot j: node, ordinal,
+    // prepared leaf state) and finally restores the tree bit for bit.  The playouts of all slots run in the same round with the
+    // RNG key of their simulation index.  Every simulation later performs its REAL selection on the committed tree and takes a
+    // slot's value only if the slot was issued for exactly (node, ordinal, this simulation index): same leaf state, same RNG key,
+    // hence the value a fresh playout would return.  Predictions therefore change timing only, never results.
+    static constexpr uint32_t VIRT_CHILD = 0xFFFFFFFFu;       // child id of an edge that exists only during the speculation pass
+    static constexpr uint32_t ORD_SELF = 0xFFFFFFFFu;         // spec_ord of slot 0: the slot's leaf is spec_node itself
+
     static TAFL_HD void consume_stats(const MctsMem& M, uint32_t g, uint32_t j, LaneStats& ls) {
         ls.rollouts += 1; ls.rollout_plies += M.spec_plies[(size_t)j * M.G + g]; ls.reason_hist4 += 1ull << (4u * (M.spec_reason[(size_t)j * M.G + g] & 15u));
     }
-    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, const K& C, LaneStats& ls) {
+
+    struct SpecLog {                                          // undo log of one speculation pass (global memory, per game)
+        UndoE* e; UndoH* h; uint32_t ne, nh, cap; bool ok;
+    };
+    static TAFL_HD void log_edge(const MctsMem& M, uint32_t g, SpecLog& L, uint32_t eidx) {
+        if (L.ne >= L.cap) { L.ok = false; return; }
+        UndoE u; u.idx = eidx; u._pad = 0; u.e = M.edges[(size_t)g * M.edge_cap + eidx];
+        L.e[L.ne++] = u;
+    }
+    static TAFL_HD void log_hdr(const MctsMem& M, uint32_t g, SpecLog& L, uint32_t node) {
+        if (L.nh >= L.cap) { L.ok = false; return; }
+        UndoH u; u.node = node; u.h = M.hdr[(size_t)node * M.G + g];
+        L.h[L.nh++] = u;
+    }
+    // assumed backup: edge `eidx` of node `cur` receives v, then the path to the root as in mcts_backup; every touched record is logged
+    static TAFL_HD void spec_backup(const MctsMem& M, uint32_t g, SpecLog& L, uint32_t cur, uint32_t eidx, double v) {
+        for (uint32_t guard = 0; guard < M.node_cap + 1 && L.ok; ++guard) {
+            log_edge(M, g, L, eidx); log_hdr(M, g, L, cur);
+            if (!L.ok) return;
+            edge_update(&M.edges[(size_t)g * M.edge_cap + eidx], v);
+            NodeHdr* ph = &M.hdr[(size_t)cur * M.G + g];
+            ph->ns += 1;
+            if (cur == 0) return;
+            const uint32_t parent = ph->parent, pslot = ph->pslot;
+            eidx = M.hdr[(size_t)parent * M.G + g].edge_base + pslot;
+            cur = parent; v = -v;
+        }
+    }
+    // Predicts the expansions of simulations first+1 .. first+want-1 after the real leaf `L` of simulation `first` became slot 0.
+    // Returns the number of slots (placeholders included).  `assumed`: value assumed for a playout in flight, seen from the leaf's mover.
+    static TAFL_HD uint32_t mcts_speculate(const MctsMem& M, uint32_t g, uint32_t leaf, uint32_t first, uint32_t want, double c_puct,
+                                           uint32_t n_sims, double assumed, const K& C, LaneStats& ls) {
+        SpecLog L; L.e = M.ulog_e + (size_t)g * M.ulog_cap; L.h = M.ulog_h + (size_t)g * M.ulog_cap; L.ne = L.nh = 0; L.cap = M.ulog_cap; L.ok = true;
+        uint32_t vtop = M.edge_top[g];                            // edge arrays that grow during the pass take free arena space, not committed
+        uint32_t cnt = 1;
+        // the pending leaf as it will be once its playout value arrives: expanded, its path updated with the assumed value
+        {
+            log_hdr(M, g, L, leaf);
+            NodeHdr* lh = &M.hdr[(size_t)leaf * M.G + g];
+            lh->expanded = 1; lh->ns = 0;
+            if (leaf != 0 && L.ok) {
+                const uint32_t parent = lh->parent;
+                spec_backup(M, g, L, parent, M.hdr[(size_t)parent * M.G + g].edge_base + lh->pslot, -assumed);
+            }
+        }
+        for (uint32_t t = 1; t < want && first + t < n_sims && L.ok; ++t) {
+            uint32_t cur = 0; bool stop = false, placed = false;
+            for (uint32_t depth = 0; depth < M.node_cap + 1; ++depth) {
+                const NodeHdr h = M.hdr[(size_t)cur * M.G + g];
+                if (h.term) {                                     // the simulation ends on a terminal node: its value is exact, no playout
+                    if (cur == 0) { stop = true; break; }
+                    spec_backup(M, g, L, h.parent, M.hdr[(size_t)h.parent * M.G + g].edge_base + h.pslot, -term_value(h.term));
+                    M.spec_kind[(size_t)t * M.G + g] = 0; placed = true;
+                    break;
+                }
+                if (!h.expanded) { stop = true; break; }
+                const int best = puct_pick(M, g, h, c_puct);
+                if (best < 0) { stop = true; break; }
+                if ((uint32_t)best < h.m) {
+                    const uint32_t child = M.edges[(size_t)g * M.edge_cap + h.edge_base + (uint32_t)best].child;
+                    if (child == VIRT_CHILD) { stop = true; break; }   // would descend into a leaf that exists only as a slot
+                    cur = child; continue;
+                }
+                // predicted expansion: child number h.m of node cur
+                S cst; IO::load_rec(M.node_state + ((size_t)cur * M.G + g) * IO::QUADS, cst);
+                Move mv; mv.from = h.cur_from; mv.to = 0; mv.dir = h.cur_dir; mv.dist = h.cur_dist;
+                if (!E::canon_next(cst, cst.flags & TAFL_F_SIDE, C, mv)) { stop = true; break; }
+                Moves<NL> nx;
+                E::apply(cst, mv, C, nullptr, nx);
+                uint32_t base = h.edge_base, cap = h.cap;
+                log_hdr(M, g, L, cur);
+                if (!L.ok) { stop = true; break; }
+                if (h.m == cap) {                                 // uncommitted growth into free arena space
+                    const uint32_t ncap = cap ? cap * 2u : 4u;
+                    if (vtop + ncap > M.edge_cap) { stop = true; break; }
+                    Edge* dst = &M.edges[(size_t)g * M.edge_cap + vtop];
+                    const Edge* src = &M.edges[(size_t)g * M.edge_cap + base];
+                    for (uint32_t j = 0; j < h.m; ++j) dst[j] = src[j];
+                    base = vtop; cap = ncap; vtop += ncap;
+                }
+                Edge ne; ne.q = 0.0; ne.n = 0; ne.child = VIRT_CHILD;
+                M.edges[(size_t)g * M.edge_cap + base + h.m] = ne;
+                NodeHdr* hp = &M.hdr[(size_t)cur * M.G + g];
+                hp->edge_base = base; hp->cap = (uint16_t)cap; hp->m = (uint16_t)(h.m + 1);
+                hp->cur_from = (uint16_t)mv.from; hp->cur_dir = (uint8_t)mv.dir; hp->cur_dist = (uint8_t)mv.dist;
+                const uint8_t tc = term_code(cst);
+                const size_t so = (size_t)t * M.G + g;
+                IO::store_rec(M.spec_state + so * IO::QUADS, cst);
+                M.spec_meta[so] = mv.from | (mv.dir << 8) | (mv.dist << 10) | (nx.total << 16);
+                M.spec_node[so] = cur; M.spec_ord[so] = h.m;
+                M.spec_kind[so] = tc ? 3 : 1;
+                if (!tc) ls.spec_issued += 1;
+                placed = true;
+                spec_backup(M, g, L, cur, base + h.m, tc ? -term_value(tc) : -assumed);
+                break;
+            }
+            if (stop || !placed) break;
+            cnt = t + 1;
+        }
+        // restore the tree (reverse order: a record may have been logged more than once)
+        for (uint32_t i = L.ne; i > 0; --i) { const UndoE u = L.e[i - 1]; M.edges[(size_t)g * M.edge_cap + u.idx] = u.e; }
+        for (uint32_t i = L.nh; i > 0; --i) { const UndoH u = L.h[i - 1]; M.hdr[(size_t)u.node * M.G + g] = u.h; }
+        return cnt;
+    }
+
+    // One call advances game g by as many simulations as it can without waiting for a playout.
+    // rounds_left: rounds the host still plans for this search (0: issue spec_k slots whenever possible): a game issues
+    // ceil(remaining / rounds_left) slots, so that a game that lost a round to a misprediction catches up instead of trailing.
+    // target: slots per game and round the plan is made for (0: none).  spec_prio: priority class of a slot in the round's work lists.
+    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, const K& C, LaneStats& ls) {
         uint32_t sim = M.sim_next[g];
-        if (M.kind[g] == 1) {                                    // slot 0 of the previous call: its playout has run
+        if (M.kind[g] == 1) {                                    // slot 0 of the previous call
+            if (M.spec_kind[g] != 2) return;                     // its playout has not run yet (the round was full): the slots stay requested
             M.rvalue[g] = M.spec_value[g];
             consume_stats(M, g, 0, ls);
             mcts_backup(M, g); ++sim;
         }
-        const uint32_t had = M.spec_n[g], first = M.spec_first[g], sparent = M.spec_parent[g];
-        const int32_t so0 = M.spec_o0[g];
+        const uint32_t had = M.spec_n[g], first = M.spec_first[g];
+        uint32_t hits = 0;
         for (;;) {
             if (sim >= n_sims) { M.spec_n[g] = 0; break; }
-            mcts_select_expand(M, g, c_puct, C, ls);
+            mcts_select_expand(M, g, sim, c_puct, C, ls);
             const uint8_t kind = M.kind[g];
             if (kind == 0) { ++sim; continue; }                                     // fault (flagged per game): nothing to back up
             if (kind == 2) { mcts_backup(M, g); ++sim; continue; }                  // terminal node: value known at once
             const uint32_t L = M.leaf[g];
-            uint32_t P = 0; int32_t ord = -1;
-            if (L != 0) { const NodeHdr lh = M.hdr[(size_t)L * M.G + g]; P = lh.parent; ord = (int32_t)lh.pslot; }
             const uint32_t j = sim - first;
-            if (had > 0 && sim > first && j < had && sparent == P && so0 + (int32_t)j == ord && M.spec_kind[(size_t)j * M.G + g] == 2) {
-                M.rvalue[g] = M.spec_value[(size_t)j * M.G + g];                  // predicted expansion: reuse its playout
-                consume_stats(M, g, j, ls); ls.spec_hits += 1;
-                mcts_backup(M, g); ++sim;
-                continue;
-            }
-            // issue new slots: slot 0 = this leaf, slots 1.. = the next unvisited children of P
-            S lst; IO::load_rec(M.node_state + ((size_t)L * M.G + g) * IO::QUADS, lst);
-            IO::store_rec(M.spec_state + (size_t)g * IO::QUADS, lst);
-            M.spec_kind[g] = 1;
-            uint32_t cnt = 1;
-            const NodeHdr ph = M.hdr[(size_t)P * M.G + g];
-            // adaptive gate: a misprediction (speculative slots left unconsumed) pauses speculation for spec_cooldown issues
-            uint32_t cool = M.spec_cool[g];
-            if (had > 1 && sim < first + had) cool = M.spec_cooldown;
-            const bool speculate = cool == 0;
-            M.spec_cool[g] = (uint8_t)(cool > 0 ? cool - 1 : 0);
-            if (speculate && M.spec_k > 1 && sim + 1 < n_sims) {
-                S pst; IO::load_rec(M.node_state + ((size_t)P * M.G + g) * IO::QUADS, pst);
-                Move cur; cur.from = ph.cur_from; cur.to = 0; cur.dir = ph.cur_dir; cur.dist = ph.cur_dist;
-                const uint32_t pside = pst.flags & TAFL_F_SIDE;
-                for (uint32_t t = 1; t < M.spec_k && sim + t < n_sims && (uint32_t)(ord + (int32_t)t) < ph.n_legal; ++t) {
-                    if (!E::canon_next(pst, pside, C, cur)) break;
-                    S cst = pst; Moves<NL> nx;
-                    E::apply(cst, cur, C, nullptr, nx);
-                    const bool term = TAFL_F_STATUS(cst.flags) != TAFL_STATUS_ONGOING;
-                    IO::store_rec(M.spec_state + ((size_t)t * M.G + g) * IO::QUADS, cst);
-                    M.spec_meta[(size_t)t * M.G + g] = cur.from | (cur.dir << 8) | (cur.dist << 10) | (nx.total << 16);
-                    M.spec_kind[(size_t)t * M.G + g] = term ? 3 : 1;
-                    if (!term) ls.spec_issued += 1;
-                    cnt = t + 1;
+            if (L != 0 && had > 0 && sim > first && j < had) {
+                const NodeHdr lh = M.hdr[(size_t)L * M.G + g];
+                const size_t so = (size_t)j * M.G + g;
+                if (M.spec_kind[so] == 2 && M.spec_node[so] == lh.parent && M.spec_ord[so] == (uint32_t)lh.pslot) {
+                    M.rvalue[g] = M.spec_value[so];                               // predicted expansion: reuse its playout
+                    consume_stats(M, g, j, ls); ls.spec_hits += 1; ++hits;
+                    mcts_backup(M, g); ++sim;
+                    continue;
                 }
             }
+            // issue new slots: slot 0 = this leaf, slots 1.. = the predicted expansions of the following simulations
+            S lst; IO::load_rec(M.node_state + ((size_t)L * M.G + g) * IO::QUADS, lst);
+            IO::store_rec(M.spec_state + (size_t)g * IO::QUADS, lst);
+            M.spec_kind[g] = 1; M.spec_node[g] = L; M.spec_ord[g] = ORD_SELF;
+            // width: what the last issue showed to be predictable (+1), capped by the slots that exist and by the deadline
+            uint32_t w = M.spec_w[g];
+            if (had > 1) {
+                uint32_t issued = 0;
+                for (uint32_t t = 1; t < had; ++t) { const uint8_t sk = M.spec_kind[(size_t)t * M.G + g]; issued += (sk == 1 || sk == 2) ? 1u : 0u; }
+#ifndef TAFL_SPEC_POLICY
+#define TAFL_SPEC_POLICY 1
+#endif
+#if TAFL_SPEC_POLICY == 0
+                w = (hits >= issued) ? w + 1u : hits + 1u;
+#elif TAFL_SPEC_POLICY == 1
+                w = (hits >= issued) ? w + 1u : ((w + hits + 1u) / 2u > hits + 1u ? (w + hits + 1u) / 2u : hits + 1u);
+#else
+                w = (hits >= issued) ? w + 1u : (hits > 0 ? (w > hits + 1u ? w : hits + 1u) : (w + 1u) / 2u);
+#endif
+            }
+            if (w > M.spec_k - 1) w = M.spec_k - 1;
+            M.spec_w[g] = (uint8_t)w;
+            // rounds_left == 1: the plan is through and only trailing games are left; the device is nearly empty, so a wasted playout
+            // costs nothing and every slot that exists is used
+            uint32_t want = M.spec_k;
+            if (rounds_left > 1) {
+                const uint32_t rem = n_sims - sim;
+                want = (rem + rounds_left - 1) / rounds_left;
+                if (want > w + 1) want = w + 1;
+            } else if (rounds_left == 0 && want > w + 1) want = w + 1;
+            if (want > M.spec_k) want = M.spec_k;
+            uint32_t cnt = 1;
+            if (want > 1 && sim + 1 < n_sims && M.ulog_cap > 0) cnt = mcts_speculate(M, g, L, sim, want, c_puct, n_sims, 0.0, C, ls);
+            for (uint32_t t = 0; t < cnt; ++t) M.spec_prio[(size_t)t * M.G + g] = (uint8_t)t;      // slot 0 (certain) first, the most speculative last
             for (uint32_t t = cnt; t < M.spec_k; ++t) M.spec_kind[(size_t)t * M.G + g] = 0;
-            M.spec_n[g] = (uint8_t)cnt; M.spec_first[g] = sim; M.spec_parent[g] = P; M.spec_o0[g] = ord;
+            M.spec_n[g] = (uint8_t)cnt; M.spec_first[g] = sim;
             break;                                                                  // wait for the playouts
         }
         M.sim_next[g] = sim;

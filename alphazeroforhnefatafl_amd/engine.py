@@ -160,9 +160,18 @@ class GameBatch:
         check(lib().tafl_mcts_reserve(self._h, max_sims))
 
     def mcts_run(self, n_sims: int, c_puct: float, seed: int, max_rollout_plies: int, game_id_base: int = 0,
-                 sim_offset: int = 0):
-        p = TaflMctsParams(n_sims, max_rollout_plies, c_puct, seed, sim_offset, 0)
+                 sim_offset: int = 0, flags: int = 0):
+        """`for i in range(numMCTSSims): self.search(canonicalBoard)` of MCTS.getActionProb (src/mcts.py:37-38) for every game.
+        `flags`: abi.MCTS_FLAG_* semantics bits | abi.mcts_tune(pipeline, slots) execution tuning (never changes results)."""
+        p = TaflMctsParams(n_sims, max_rollout_plies, c_puct, seed, sim_offset, flags)
         check(lib().tafl_mcts_run(self._h, C.byref(p), game_id_base))
+
+    def mcts_round_trace(self, cap: int = 4096):
+        """(requested, run) playouts of every round of the last search (measurement; the two-kernel pipeline only)."""
+        req, run, k = (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), C.c_uint32()
+        check(lib().tafl_mcts_round_trace(self._h, req, run, cap, C.byref(k)))
+        m = min(k.value, cap)
+        return list(req[:m]), list(run[:m])
 
     def mcts_stats(self) -> TaflMctsStats:
         st = TaflMctsStats()

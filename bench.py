@@ -191,17 +191,17 @@ def mcts_bytes_per_sim(stats, side):
     return d_bar * (64 + 16 * c_bar) + 32 + 2 * SG_BYTES[side] + 4, d_bar, c_bar
 
 
-def timed_mcts(logic, batch, sims, cpuct, seed, cap, base, steps, warmup, sync):
+def timed_mcts(logic, batch, sims, cpuct, seed, cap, base, steps, warmup, sync, flags=0):
     """W warm-up + K timed mcts_run steps on an existing batch; returns (elapsed_s, stats, kernel-class timings)."""
     from alphazeroforhnefatafl_amd.engine import KC_MCTS_BACKUP, KC_MCTS_ROLLOUT, KC_MCTS_TREE
     for _ in range(warmup):
-        batch.mcts_run(sims, cpuct, seed, cap, game_id_base=base)
+        batch.mcts_run(sims, cpuct, seed, cap, game_id_base=base, flags=flags)
     sync()
     logic.timing_reset()
     logic.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        batch.mcts_run(sims, cpuct, seed, cap, game_id_base=base)
+        batch.mcts_run(sims, cpuct, seed, cap, game_id_base=base, flags=flags)
     sync()
     elapsed = time.perf_counter() - t0
     logic.timing_enable(False)
@@ -346,6 +346,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` object (S=256/1000, 13x13, streamed kernels)")
     ap.add_argument("--board", default="copenhagen11", choices=list(BOARDS),
                     help="copenhagen11 = the headline workload (BASELINE configs[2]); copenhagen13 = configs[4] (U256 multi-word path)")
+    ap.add_argument("--pipeline", type=int, default=0, help="tuning: MCTS pipeline (0 default, 1 fused kernel, 2 two-kernel); results do not depend on it")
+    ap.add_argument("--slots", type=int, default=0, help="tuning: playout slots per game the search is planned for (0 = from the batch size)")
+    ap.add_argument("--parts", type=int, default=0, help="tuning: partitions of the batch on their own streams (0 = from the batch size)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend for the barrier / reductions (default nccl = RCCL; gloo with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0 (barrier over gloo)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: every rank joins the gloo group, "
@@ -409,7 +412,8 @@ def main():
         tdist.barrier(world)
         torch.cuda.synchronize()
 
-    my_elapsed, stats, kt = timed_mcts(logic, batch, args.sims, args.cpuct, args.seed, args.max_plies, base, args.steps, args.warmup, barrier)
+    my_elapsed, stats, kt = timed_mcts(logic, batch, args.sims, args.cpuct, args.seed, args.max_plies, base, args.steps, args.warmup, barrier,
+                                       flags=abi.mcts_tune(args.pipeline, args.slots, args.parts))
     if stats.sims != G * args.sims or stats.faults != 0:
         raise SystemExit(f"rank {rank}: the last step ran {stats.sims} simulations with {stats.faults} faults, expected {G * args.sims} / 0")
     elapsed = tdist.max_over_ranks(my_elapsed, world, device=red_dev)
@@ -442,7 +446,7 @@ def main():
                                    f": full MCTS (select/expand/random-rollout/backup), {G} concurrent {side_}x{side_} "
                                    f"{args.board} games per GPU from the start position" + (f"; x{world} GPUs = configs[3]" if headline and world == 8 else ""),
                        "games_per_gpu": G, "games_total": G * world, "sims_per_root": args.sims, "max_rollout_plies": args.max_plies,
-                       "c_puct": args.cpuct, "seed": args.seed, "sharding": f"game-id ranges x{world}, no collectives",
+                       "c_puct": args.cpuct, "seed": args.seed, "pipeline": args.pipeline, "slots": args.slots, "sharding": f"game-id ranges x{world}, no collectives",
                        "launcher": "bench.py child processes" if os.environ.get("TAFL_BENCH_CHILD") else ("torch.distributed.run" if has_env else "single process"),
                        "single_device_rehearsal": bool(args.single_device)},
             "per_rank_sims_per_sec": [G * args.sims * args.steps / t for t in per_rank],

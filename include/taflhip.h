@@ -195,8 +195,25 @@ typedef struct tafl_mcts_params {
     double   c_puct;           /* args.cpuct         src/mcts.py:112 */
     uint64_t seed;
     uint32_t sim_offset;       /* first simulation index used in the RNG key (normally 0) */
-    uint32_t flags;            /* reserved, must be 0 */
+    uint32_t flags;            /* TAFL_MCTS_FLAG_* | tuning fields; 0 = src/mcts.py semantics, default pipeline */
 } tafl_mcts_params;
+/* tuning fields of tafl_mcts_params.flags: they choose HOW the same search is executed and never change its results
+ * (tests/test_gpu_parity.py::test_mcts_pipelines_agree).
+ *   bits 4-7   pipeline: 0 default (two kernels per round: tree phase + playouts over a dense work list), 1 fused (one kernel per
+ *              chunk of rounds, at most 2 playout slots per game), 2 two-kernel (explicit)
+ *   bits 8-11  playout slots per game in flight (slot 0 = the pending simulation, the rest are predicted simulations, DESIGN.md
+ *              section 6); 0 = chosen from the batch size, at most 8
+ *   bits 12-15 partitions of the batch that run the pipeline on their own streams (two-kernel pipeline); 0 = from the batch size, at most 8 */
+#define TAFL_MCTS_PIPELINE_DEFAULT 0u
+#define TAFL_MCTS_PIPELINE_FUSED 1u
+#define TAFL_MCTS_PIPELINE_TWO_KERNEL 2u
+#define TAFL_MCTS_TUNE_PIPELINE(x) (((uint32_t)(x) & 15u) << 4)
+#define TAFL_MCTS_TUNE_SLOTS(x) (((uint32_t)(x) & 15u) << 8)
+#define TAFL_MCTS_TUNE_PARTS(x) (((uint32_t)(x) & 15u) << 12)
+#define TAFL_MCTS_TUNE_PARTS_OF(f) (((f) >> 12) & 15u)
+#define TAFL_MCTS_TUNE_PIPELINE_OF(f) (((f) >> 4) & 15u)
+#define TAFL_MCTS_TUNE_SLOTS_OF(f) (((f) >> 8) & 15u)
+#define TAFL_MCTS_FLAGS_KNOWN 0x0000FFF0u
 
 typedef struct tafl_mcts_stats {
     uint64_t sims;             /* simulations executed (all games) */
@@ -368,6 +385,8 @@ int tafl_replay_read(const char* path, uint8_t side_len, uint32_t max_records, u
 /* ---- measurement helpers (bench.py) -----------------------------------------------------------------
  * HIP-event timing on the ctx stream: average duration of the named kernel class since the last reset.
  * classes: 0 movegen, 1 step, 2 rollout, 3 mcts_select_expand, 4 mcts_rollout, 5 mcts_backup */
+int tafl_mcts_round_trace(tafl_batch* b, uint32_t* requested, uint32_t* run, uint32_t cap, uint32_t* n_rounds); /* playouts requested /
+    run in each round of the last tafl_mcts_run (two-kernel pipeline; 0 rounds after a fused search); arrays may be NULL */
 int tafl_timing_enable(tafl_ctx* ctx, int enable);
 int tafl_timing_reset(tafl_ctx* ctx);
 int tafl_timing_get(tafl_ctx* ctx, int kernel_class, double* total_ms, uint64_t* launches);

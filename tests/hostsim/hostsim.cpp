@@ -13,8 +13,10 @@
 
 using namespace tafl;
 
-static uint32_t g_spec_cooldown = 0;   // see MctsMem::spec_cool
-static uint32_t g_spec_k = 2;          // playout slots per game in the MCTS pipeline (1 = no speculation)
+static uint32_t g_spec_k = 4;          // playout slots per game that exist in the MCTS pipeline (1 = no speculation)
+static uint32_t g_spec_target = 0;     // slots per game and round the search is planned for (0: no plan, issue what is allowed)
+static uint32_t g_capacity = 0;        // playouts a round may run (0: all that are requested), like the device capacity of k_mcts_rollout
+static std::vector<uint32_t> g_round_work;   // playouts executed per round of the last hs_mcts call (cost-model experiments)
 static bool g_force_generic = false;   // differential tests: generic Engine::rollout vs the fast playout engine
 
 template <int NL, int W>
@@ -70,24 +72,28 @@ struct Host {
                     tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) {
         K C; if (consts(r, n, C)) return -1;
         using IO = StateIO<NL>;
-        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k; M.spec_cooldown = g_spec_cooldown;
+        // same host loop as tafl_mcts_run's two-kernel pipeline: g_spec_k slots exist per game, the search is planned for
+        // ceil(n_sims / g_spec_target) rounds (g_spec_target = 0: every game issues as many slots as it may, every round)
+        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k; M.ulog_cap = g_spec_k > 1 ? 64 : 0;
         std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS), sst((size_t)M.spec_k * G * IO::QUADS);
         std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
         std::vector<Edge> edges((size_t)M.edge_cap * G);
-        std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sparent(G), sfirst(G), splies((size_t)M.spec_k * G), smeta((size_t)M.spec_k * G);
-        std::vector<int32_t> so0(G);
-        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), scool(G);
+        std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sfirst(G), splies((size_t)M.spec_k * G), smeta((size_t)M.spec_k * G), snode((size_t)M.spec_k * G), sord((size_t)M.spec_k * G);
+        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), sw(G), sprio((size_t)M.spec_k * G);
         std::vector<int8_t> rv(G), sval((size_t)M.spec_k * G);
+        std::vector<UndoE> ue((size_t)(M.ulog_cap ? M.ulog_cap : 1) * G); std::vector<UndoH> uh((size_t)(M.ulog_cap ? M.ulog_cap : 1) * G);
         M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
         M.leaf = leaf.data(); M.kind = kind.data(); M.rvalue = rv.data(); M.fault = fault.data();
         M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data(); M.spec_meta = smeta.data();
-        M.spec_plies = splies.data(); M.spec_parent = sparent.data(); M.spec_o0 = so0.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_cool = scool.data();
+        M.spec_plies = splies.data(); M.spec_node = snode.data(); M.spec_ord = sord.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_w = sw.data(); M.spec_prio = sprio.data();
+        M.ulog_e = ue.data(); M.ulog_h = uh.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; state_from_abi<NL>(st[g], s); O::mcts_init_game(M, g, s, C); }
-        auto tree = [&]() {
+        g_round_work.clear();
+        auto tree = [&](uint32_t rounds_left) {
             for (uint32_t g = 0; g < G; ++g) {
                 LaneStats ls; memset(&ls, 0, sizeof ls);
-                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, C, ls);
+                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, rounds_left, g_spec_target, C, ls);
                 stats->sims += ls.sims; stats->tree_depth_sum += ls.depth; stats->children_scanned += ls.scanned;
                 stats->terminal_hits += ls.terminal_hits; stats->faults += ls.faults;
                 stats->rollouts += ls.rollouts; stats->rollout_plies += ls.rollout_plies;
@@ -95,13 +101,25 @@ struct Host {
                 stats->spec_issued += ls.spec_issued; stats->spec_hits += ls.spec_hits;
             }
         };
-        for (uint32_t i = 0; i < p->n_sims; ++i) {
-            tree();
-            for (uint32_t j = 0; j < M.spec_k; ++j)
-                for (uint32_t g = 0; g < G; ++g) O::mcts_slot_rollout(M, j, g, p->seed, base + g, p->sim_offset, p->max_rollout_plies, C);
+        const uint32_t planned = g_spec_target ? (p->n_sims + g_spec_target - 1) / g_spec_target : 0;
+        for (uint32_t i = 0; i < (p->n_sims + 2) * (g_capacity ? 1 + G / g_capacity : 1); ++i) {
+            tree(g_spec_target ? (i < planned ? planned - i : 1u) : 0u);
+            // slot-major like the device's per-slot work lists; with a capacity, playouts beyond it wait for the next round
+            uint32_t work = 0;
+            for (uint32_t pr = 0; pr < M.spec_k; ++pr)
+                for (uint32_t j = 0; j < M.spec_k; ++j)
+                    for (uint32_t g = 0; g < G; ++g) {
+                        if (!(j < sn[g] && skind[(size_t)j * G + g] == 1 && sprio[(size_t)j * G + g] == pr)) continue;
+                        if (g_capacity && work >= g_capacity) continue;
+                        ++work; O::mcts_slot_rollout(M, j, g, p->seed, base + g, p->sim_offset, p->max_rollout_plies, C);
+                    }
+            if (work == 0) break;
+            g_round_work.push_back(work);
         }
-        tree();
         for (uint32_t g = 0; g < G; ++g) if (simn[g] != p->n_sims) return -3;
+        // the speculation pass must leave no trace: no edge may point at a slot-only child
+        for (uint32_t g = 0; g < G; ++g)
+            for (uint32_t k = 0; k < ntop[g]; ++k) { const NodeHdr& h = hdr[(size_t)k * G + g]; for (uint32_t j = 0; j < h.m; ++j) if (edges[(size_t)g * M.edge_cap + h.edge_base + j].child >= ntop[g]) return -4; }
         for (uint32_t g = 0; g < G; ++g) {
             const uint32_t k = O::mcts_root_children(M, g, C, out_children + (size_t)g * max_children, max_children);
             if (out_n) out_n[g] = k;
@@ -188,7 +206,9 @@ void hs_gmcts_root_children(void* h, tafl_root_child* out, uint32_t max_children
 void hs_gmcts_counts(void* h, uint64_t* out4) { GSessionBase* s = (GSessionBase*)h; out4[0] = s->sims; out4[1] = s->predicts; out4[2] = s->terminal_hits; out4[3] = s->faults; }
 void hs_force_generic(int on) { g_force_generic = on != 0; }
 void hs_set_spec_k(uint32_t k) { g_spec_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
-void hs_set_spec_cooldown(uint32_t c) { g_spec_cooldown = c > 200 ? 200 : c; }
+void hs_set_spec_target(uint32_t t) { g_spec_target = t > 8 ? 8 : t; }
+void hs_set_capacity(uint32_t c) { g_capacity = c; }
+uint32_t hs_round_work(uint32_t* out, uint32_t cap) { const uint32_t n = (uint32_t)g_round_work.size(); for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = g_round_work[i]; return n; }
 int hs_movegen(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint32_t* counts, uint32_t* masks, uint32_t mw) { DISPATCH(movegen(r, n, st, cnt, counts, masks, mw)) }
 int hs_validate(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_play* plays, uint8_t* codes) { DISPATCH(validate(r, n, st, cnt, plays, codes)) }
 int hs_step(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const tafl_play* plays, tafl_effects* eff) { DISPATCH(step(r, n, st, cnt, plays, eff)) }

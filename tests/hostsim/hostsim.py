@@ -45,8 +45,12 @@ def lib():
         L.hs_gmcts_root_children.argtypes = [vp, P(TaflRootChild), u32, P(u32)]
         L.hs_gmcts_counts.restype = None
         L.hs_gmcts_counts.argtypes = [vp, P(u64)]
-        L.hs_set_spec_cooldown.restype = None
-        L.hs_set_spec_cooldown.argtypes = [C.c_uint32]
+        L.hs_set_spec_target.restype = None
+        L.hs_set_spec_target.argtypes = [C.c_uint32]
+        L.hs_set_capacity.restype = None
+        L.hs_set_capacity.argtypes = [C.c_uint32]
+        L.hs_round_work.restype = C.c_uint32
+        L.hs_round_work.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
         L.hs_set_spec_k.restype = None
         L.hs_set_spec_k.argtypes = [C.c_uint32]
         L.hs_force_generic.restype = None
@@ -113,7 +117,17 @@ def force_generic(on: bool):
     lib().hs_force_generic(int(on))
 
 
-def set_spec_k(k: int, cooldown: int = 0):
-    """Playout slots per game of the MCTS pipeline in host-sim runs (1 = no speculation) and the misprediction cooldown."""
+def set_spec_k(k: int, target: int = 0, capacity: int = 0):
+    """Playout slots per game that exist in host-sim MCTS runs (1 = no speculation), the slots per game and round the
+    search is planned for (0 = no plan: every game issues what its own hit history allows), and the playouts one round may
+    run (0 = all requested; otherwise the rest waits for the next round, as on a full device)."""
     lib().hs_set_spec_k(k)
-    lib().hs_set_spec_cooldown(cooldown)
+    lib().hs_set_spec_target(target)
+    lib().hs_set_capacity(capacity)
+
+
+def round_work():
+    """Playouts executed in each round of the last HostSim.mcts call."""
+    buf = (C.c_uint32 * 4096)()
+    n = lib().hs_round_work(buf, 4096)
+    return list(buf[:min(n, 4096)])

@@ -478,28 +478,36 @@ def test_training_tensor_writers():
 
 
 @pytest.mark.parametrize("name,G,sims", [("copenhagen11", 200, 70), ("brandubh7", 130, 150), ("copenhagen13", 70, 40)])
-def test_fused_and_two_kernel_mcts_paths_agree(name, G, sims, monkeypatch):
-    """The default fused kernel (k_mcts_fused) and the two-kernel pipeline (TAFL_MCTS_FUSED=0: k_mcts_tree + k_mcts_rollout with the
-    dense work list) run the same per-game functions: identical root statistics and counters, for 1 and 2 playout slots per game.
-    The switches are read when a batch is created."""
+def test_mcts_pipelines_agree(name, G, sims):
+    """The tuning fields of tafl_mcts_params.flags choose HOW a search runs, never its results: the default two-kernel pipeline
+    (k_mcts_tree + k_mcts_rollout over the dense work list) with 1 .. 8 playout slots per game and the fused kernel
+    (k_mcts_fused, 1 or 2 slots) run the same per-game functions: identical root statistics and counters."""
     rules, fen, wb, n, lg = _mk(name)
     states = pu.start_states(orc, fen, rules.starting_side, wb, G)
     plies = (C.c_uint32 * G)(*[(i * 3) % 50 for i in range(G)])
     orc.batch_random_advance(lg, states, G, wb, 19, plies, 5)
     results = []
-    for fused, k in (("1", "2"), ("0", "2"), ("1", "1"), ("0", "1")):
-        monkeypatch.setenv("TAFL_MCTS_FUSED", fused)
-        monkeypatch.setenv("TAFL_SPEC_K", k)
+    tunes = [abi.mcts_tune(0, 0), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 1), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 2),
+             abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 5), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 8),
+             abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 4, 3), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 0, 1),
+             abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 2), abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 1)]
+    for flags in tunes:
         b = gpu_batch(rules, n, wb, states, G)
-        b.mcts_run(sims, 1.0, 3, 300, game_id_base=5)
+        b.mcts_run(sims, 1.0, 3, 300, game_id_base=5, flags=flags)
         kids, cnt = b.mcts_root_children(256)
         st = b.mcts_stats()
         results.append(([(kids[g * 256 + j].action, kids[g * 256 + j].visits, float(kids[g * 256 + j].q).hex()) for g in range(G) for j in range(cnt[g])],
                         list(cnt), (st.sims, st.rollouts, st.rollout_plies, st.tree_depth_sum, st.children_scanned, st.terminal_hits, st.faults),
                         list(st.reason_hist)))
+        if flags == abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 1):
+            assert st.spec_issued == 0 and st.spec_hits == 0
         b.close()
     for r in results[1:]:
         assert r == results[0]
+    with pytest.raises(Exception):
+        gpu_batch(rules, n, wb, states, G).mcts_run(sims, 1.0, 3, 300, flags=abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 4))
+    with pytest.raises(Exception):
+        gpu_batch(rules, n, wb, states, G).mcts_run(sims, 1.0, 3, 300, flags=1 << 20)
 
 
 def test_batched_game_history_and_undo():

@@ -140,10 +140,11 @@ def test_mcts(name, sims, cpuct):
     assert list(ostats.reason_hist) == list(hstats.reason_hist)
 
 
-@pytest.mark.parametrize("k,cooldown", [(1, 2), (2, 0), (2, 2), (3, 1), (4, 5), (8, 0)])
+@pytest.mark.parametrize("k,cooldown", [(1, 0), (2, 0), (2, 1), (3, 2), (4, 0), (4, 4), (8, 0), (8, 3), (8, 8)])
 def test_mcts_speculative_slots_do_not_change_results(k, cooldown):
-    """The MCTS pipeline with k playout slots per game (k-1 speculative) must reproduce the sequential search exactly:
-    root statistics as float64 bit patterns and every counter, for start, mid-game and terminal-heavy positions."""
+    """The MCTS pipeline with k playout slots per game (k-1 predicted simulations, `cooldown` = slots per round the search is planned
+    for) must reproduce the sequential search exactly: root statistics as float64 bit patterns and every counter, for start,
+    mid-game and terminal-heavy positions.  The host-sim driver also checks that the speculation pass leaves no trace in the tree."""
     import json
     import os
     from tests.hostsim import hostsim
@@ -183,4 +184,34 @@ def test_mcts_speculative_slots_do_not_change_results(k, cooldown):
         assert list(ostats.reason_hist) == list(hstats.reason_hist)
         assert ostats.terminal_hits > 0
     finally:
-        hostsim.set_spec_k(2, 0)
+        hostsim.set_spec_k(4, 0, 0)
+
+
+@pytest.mark.parametrize("k,target,capacity", [(8, 4, 70), (8, 0, 40), (4, 4, 33), (8, 8, 1), (2, 2, 20)])
+def test_mcts_with_a_full_device_round_capacity(k, target, capacity):
+    """More playouts requested than one round may run (the device holds occupancy x CUs x 64 lanes at once): the rest waits for the
+    next round, slot 0 of every waiting game first.  Same results as the sequential search, bit for bit."""
+    from tests.hostsim import hostsim
+    rules, fen, wb = pu.CONFIGS["brandubh7"]
+    n, G = 7, 32
+    lg, hs = orc.GameLogic(rules, n), HostSim(rules, n, wb)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 7) % 30 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 23, plies, 9)
+    p = TaflMctsParams(48, 64, 1.25, 6, 0, 0)
+    ok, on, ostats = orc.batch_mcts(lg, states, G, wb, p, 9)
+    hostsim.set_spec_k(k, target, capacity)
+    try:
+        hk, hn, hstats = hs.mcts(states, G, p, 9)
+        work = hostsim.round_work()
+    finally:
+        hostsim.set_spec_k(4, 0, 0)
+    assert max(work) <= capacity
+    assert list(on) == list(hn)
+    for g in range(G):
+        for j in range(on[g]):
+            a, b = ok[g * 256 + j], hk[g * 256 + j]
+            assert (a.action, a.visits, float(a.q).hex()) == (b.action, b.visits, float(b.q).hex()), (g, j)
+    for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+        assert getattr(ostats, f) == getattr(hstats, f), f
+    assert list(ostats.reason_hist) == list(hstats.reason_hist)
