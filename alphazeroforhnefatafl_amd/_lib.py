@@ -53,12 +53,14 @@ SYMBOLS = [
     ("tafl_mcts_play_best", _i32, [_vp, _P(TaflPlay), _P(TaflEffects)]),
     ("tafl_encode_boards", _i32, [_vp, _vp, _i32]),
     ("tafl_mcts_policy_device", _i32, [_vp, _dbl, _vp, _i32]),
+    ("tafl_mcts_policy_device_ex", _i32, [_vp, _dbl, _u64, _u64, _vp, _i32]),
     ("tafl_gmcts_begin", _i32, [_vp, _u32, _u32]),
     ("tafl_gmcts_step", _i32, [_vp, _vp, _vp, _i32, _dbl, _u32, _P(_u32)]),
     ("tafl_gmcts_leaves", _i32, [_vp, _vp, _vp, _vp, _i32]),
     ("tafl_gmcts_root_children", _i32, [_vp, _P(TaflRootChild), _u32, _P(_u32)]),
     ("tafl_gmcts_root_visits", _i32, [_vp, _vp, _i32]),
     ("tafl_gmcts_policy", _i32, [_vp, _dbl, _vp, _i32]),
+    ("tafl_gmcts_policy_ex", _i32, [_vp, _dbl, _u64, _u64, _vp, _i32]),
     ("tafl_gmcts_get_stats", _i32, [_vp, _P(TaflGmctsStats)]),
     ("tafl_replay_append", _i32, [C.c_char_p, _P(_u8), _u8, _P(_u8), _u32, _u8, _u8, _u64]),
     ("tafl_replay_append_batch", _i32, [C.c_char_p, _P(_u8), _u8, _u32, _P(_u8), _P(_u32), _P(_u8), _P(_u8), _u64]),

@@ -54,6 +54,7 @@ ROLLOUT_REASON_STUCK = 15
 MAX_LIMBS = 4
 
 # tafl_mcts_params.flags (include/taflhip.h): tuning fields choose how a search is executed, never what it returns
+MCTS_FLAG_FPU_INF = 0x1          # src/mcts.rs:49-51,187: unvisited actions score +inf, new nodes start with visits 1 (oracle-pinned only)
 MCTS_PIPELINE_DEFAULT, MCTS_PIPELINE_FUSED, MCTS_PIPELINE_TWO_KERNEL = 0, 1, 2
 
 

@@ -383,23 +383,46 @@ __global__ __launch_bounds__(256) void k_encode_boards(Consts<NL> C, const Quad*
     out[i] = (uint8_t)v;
 }
 
-// probs of src/mcts.py:48-53 at temp == 1 (counts / float(sum(counts)), exact in float64) or temp == 0 (one-hot on the first maximum)
+// probs of src/mcts.py:43-53 for any temperature.
+//   temp > 0 : counts ** (1 / temp) (float64 pow of the device math library; exactly the count for temp == 1), summed in ascending action
+//              order like Python's sum(), then divided (mcts.py:50-52).
+//   temp == 0: one-hot on one of the maxima (mcts.py:44-48).  The reference draws it with the process-global np.random.choice; here it is
+//              the first maximum (tie_seed == 0) or the (r mod ties)-th one in ascending action order with r = the taflmix32 word keyed by
+//              (tie_seed, global game id): reproducible and independent of the sharding.
+__device__ __forceinline__ uint32_t tie_pick(uint64_t tie_seed, uint64_t game_id, uint32_t ties) {
+    const uint64_t gk = Engine<2, 7>::game_key(tie_seed, game_id);
+    const uint32_t h = Engine<2, 7>::fmix32((uint32_t)gk ^ Engine<2, 7>::fmix32((uint32_t)(gk >> 32) + 0x7A1E5EEDu));
+    return Engine<2, 7>::mulhi(h, ties);
+}
+__device__ __forceinline__ double temp_weight(uint32_t n, double inv_temp) { return inv_temp == 1.0 ? (double)n : pow((double)n, inv_temp); }
+
 template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_policy(Consts<NL> C, MctsMem M, double* out, uint32_t action_size, int one_hot) {
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_policy(Consts<NL> C, MctsMem M, double* out, uint32_t action_size, int one_hot, double inv_temp,
+                                                            uint64_t tie_seed, uint64_t base) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= M.G) return;
     const NodeHdr h = M.hdr[g];
     const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
-    double sum = 0.0; uint32_t best = 0, arg = 0;
-    for (uint32_t j = 0; j < h.m; ++j) { const Edge e = eb[j]; sum += (double)e.n; if (e.n > best) { best = e.n; arg = j; } }
+    double sum = 0.0; uint32_t best = 0, ties = 0;
+    for (uint32_t j = 0; j < h.m; ++j) {
+        const Edge e = eb[j];
+        if (!one_hot) sum += temp_weight(e.n, inv_temp);
+        if (e.n > best) { best = e.n; ties = 1; } else if (e.n == best && best > 0) ++ties;
+    }
+    uint32_t pick = 0;
+    if (one_hot && tie_seed != 0 && ties > 1) pick = tie_pick(tie_seed, base + g, ties);
+    uint32_t seen = 0;
     for (uint32_t j = 0; j < h.m; ++j) {
         const Edge e = eb[j];
         const NodeHdr ch = M.hdr[(size_t)e.child * M.G + g];
         Move m; m.from = ch.mv_from; m.dir = ch.mv_dir; m.dist = ch.mv_dist; m.to = 0;
-        const double p = one_hot ? ((j == arg && best > 0) ? 1.0 : 0.0) : (double)e.n / sum;
+        double p;
+        if (one_hot) { const bool is_max = best > 0 && e.n == best; p = (is_max && seen == pick) ? 1.0 : 0.0; seen += is_max ? 1u : 0u; }
+        else p = temp_weight(e.n, inv_temp) / sum;
         out[(size_t)g * action_size + Ops<NL, W>::action_of(m, C)] = p;
     }
-    if (one_hot && best == 0) out[(size_t)g * action_size] = 1.0;          // all counts zero: argmax of zeros = action 0 (np.argwhere order)
+    // all counts zero (the root was terminal): every action is a maximum (np.argwhere order); first, or the seeded choice among all actions
+    if (one_hot && best == 0) out[(size_t)g * action_size + (tie_seed != 0 ? tie_pick(tie_seed, base + g, action_size) : 0u)] = 1.0;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -426,6 +449,7 @@ struct tafl_ctx {
     hipStream_t part_stream[TAFL_MCTS_MAX_PARTS];   // streams of the partitioned MCTS pipeline ([0] = stream; the others are created on first use)
     hipEvent_t ev_fork[TAFL_MCTS_MAX_PARTS], ev_join[TAFL_MCTS_MAX_PARTS];
     uint32_t n_part_streams;
+    uint32_t live_batches;           // batches created on this context and not yet destroyed (tafl_ctx_destroy refuses while > 0)
     uint32_t rollout_capacity;       // playouts k_mcts_rollout holds on the device at once (occupancy x CUs x 64 lanes); 0 = not asked yet
     bool timing;
     std::vector<TimedSpan> spans;
@@ -535,8 +559,8 @@ int tafl_ctx_create(const tafl_rules* rules, uint8_t side_len, uint32_t word_bit
     tafl_ctx* c = new (std::nothrow) tafl_ctx();
     if (!c) return fail(TAFL_ERR_OOM, "out of host memory");
     c->rules = *rules; c->n = side_len; c->word_bits = word_bits; c->nl = (uint32_t)l64 * 2; c->w = (uint32_t)rw; c->device = device;
-    c->timing = false; c->rollout_capacity = 0; c->n_part_streams = 0;
-    c->preset = getenv("TAFL_NO_PRESET") ? PRESET_NONE : detect_preset(*rules, side_len, word_bits);
+    c->timing = false; c->rollout_capacity = 0; c->n_part_streams = 0; c->live_batches = 0;
+    c->preset = detect_preset(*rules, side_len, word_bits);
     for (int i = 0; i < KC_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
     int rc = 0;
     if (c->nl == 2) rc = make_consts<2, 7>(*rules, side_len, c->c2);
@@ -551,6 +575,7 @@ int tafl_ctx_create(const tafl_rules* rules, uint8_t side_len, uint32_t word_bit
 
 int tafl_ctx_destroy(tafl_ctx* c) {
     if (!c) return TAFL_OK;
+    if (c->live_batches != 0) return fail(TAFL_ERR_INVALID_ARG, "tafl_ctx_destroy: batches of this context are still alive (destroy them first)");
     (void)hipSetDevice(c->device);
     drain_spans(c);
     for (uint32_t k = 1; k < c->n_part_streams; ++k) {
@@ -617,12 +642,14 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
     if (hipMalloc((void**)&b->soa, bytes) != hipSuccess) { delete b; return fail(TAFL_ERR_OOM, "hipMalloc(batch states) failed"); }
     if (hipMemsetAsync(b->soa, 0, bytes, c->stream) != hipSuccess) { (void)hipFree(b->soa); delete b; return fail(TAFL_ERR_HIP, "hipMemsetAsync failed"); }
+    c->live_batches += 1;
     *out = b;
     return TAFL_OK;
 }
 
 int tafl_batch_destroy(tafl_batch* b) {
     if (!b) return TAFL_OK;
+    if (b->ctx->live_batches > 0) b->ctx->live_batches -= 1;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     if (b->soa) (void)hipFree(b->soa);
@@ -662,7 +689,7 @@ int tafl_batch_reset_fen(tafl_batch* b, const char* fen, uint8_t side) {
 }
 
 int tafl_batch_upload(tafl_batch* b, const tafl_state* states, uint32_t first, uint32_t count) {
-    if (!b || !states || first + count > b->n || count == 0) return fail(TAFL_ERR_INVALID_ARG, "bad range");
+    if (!b || !states || count == 0 || first > b->n || count > b->n - first) return fail(TAFL_ERR_INVALID_ARG, "bad range");
     tafl_ctx* c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int Q = quads_of(c);
@@ -680,7 +707,7 @@ int tafl_batch_upload(tafl_batch* b, const tafl_state* states, uint32_t first, u
 }
 
 int tafl_batch_download(tafl_batch* b, tafl_state* states, uint32_t first, uint32_t count) {
-    if (!b || !states || first + count > b->n || count == 0) return fail(TAFL_ERR_INVALID_ARG, "bad range");
+    if (!b || !states || count == 0 || first > b->n || count > b->n - first) return fail(TAFL_ERR_INVALID_ARG, "bad range");
     tafl_ctx* c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     const int Q = quads_of(c);
@@ -843,6 +870,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_w = (uint8_t*)b->spec_w.p; b->mem.spec_prio = (uint8_t*)b->spec_prio.p; b->mem.spec_k = b->spec_k;
     b->mem.ulog_e = (UndoE*)b->ulog_e.p; b->mem.ulog_h = (UndoH*)b->ulog_h.p; b->mem.ulog_cap = TAFL_MCTS_UNDO_CAP;
     b->mem.G = b->n; b->mem.node_cap = (uint32_t)node_cap; b->mem.edge_cap = (uint32_t)edge_cap;
+    b->mem.flags = 0;
     b->has_mem = true; b->reserved_sims = max_sims;
     return TAFL_OK;
 }
@@ -856,7 +884,7 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     tafl_ctx* c = b->ctx; const uint32_t n = b->n;
     HIPCHK(hipSetDevice(c->device));
     MctsMem M = b->mem;
-    M.node_cap = p->n_sims + 1; M.edge_cap = b->mem.edge_cap;
+    M.node_cap = p->n_sims + 1; M.edge_cap = b->mem.edge_cap; M.flags = p->flags & TAFL_MCTS_FLAG_FPU_INF;
     unsigned long long* st = (unsigned long long*)b->stats.p;
     HIPCHK(hipMemsetAsync(st, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
     // tuning fields of `flags` (results never depend on them): pipeline and playout slots per game
@@ -1133,20 +1161,23 @@ int tafl_encode_boards(tafl_batch* b, uint8_t* out, int out_is_device) {
     return TAFL_OK;
 }
 
-int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_device) {
+int tafl_mcts_policy_device_ex(tafl_batch* b, double temp, uint64_t tie_seed, uint64_t game_id_base, double* out, int out_is_device) {
     if (!b || !out || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
-    if (!(temp == 0.0 || temp == 1.0)) return fail(TAFL_ERR_UNSUPPORTED, "device policy writer supports temp 0 and 1 (use tafl_mcts_policy for other temperatures)");
+    if (!(temp >= 0.0)) return fail(TAFL_ERR_INVALID_ARG, "temp must be >= 0");
     tafl_ctx* c = b->ctx; const uint32_t n = b->n, as = tafl_action_size(c); const size_t bytes = sizeof(double) * (size_t)n * as;
     HIPCHK(hipSetDevice(c->device));
     double* dst = out;
     if (!out_is_device) { NEED(b->policy, bytes); dst = (double*)b->policy.p; }
     HIPCHK(hipMemsetAsync(dst, 0, bytes, c->stream));
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_policy<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, dst, as, temp == 0.0 ? 1 : 0));
+    const double inv = temp == 0.0 ? 1.0 : 1.0 / temp;                  // 1. / temp of mcts.py:50
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_policy<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, dst, as, temp == 0.0 ? 1 : 0, inv,
+                                       tie_seed, game_id_base));
     HIPCHK(hipGetLastError());
     if (!out_is_device) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return TAFL_OK;
 }
+int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_device) { return tafl_mcts_policy_device_ex(b, temp, 0, 0, out, out_is_device); }
 
 }  // extern "C"
 
@@ -1199,20 +1230,35 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_gmcts_root_children(Consts<NL> C
     if (g >= M.G) return;
     out_n[g] = Guided<NL, W>::root_children(M, g, out + (size_t)g * max_children, max_children);
 }
-// dense root visit counts and the probs of src/mcts.py:48-53 (temp 1: counts / float(sum), temp 0: one-hot on the first maximum)
+// dense root visit counts and the probs of src/mcts.py:43-53 (any temperature; temp == 0 as in k_mcts_policy)
 template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_gmcts_root_dense(Consts<NL> C, GuidedMem M, uint32_t* visits, double* probs, uint32_t A, int one_hot) {
+__global__ __launch_bounds__(TAFL_BLOCK) void k_gmcts_root_dense(Consts<NL> C, GuidedMem M, uint32_t* visits, double* probs, uint32_t A, int one_hot, double inv_temp,
+                                                                 uint64_t tie_seed, uint64_t base) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= M.G) return;
     const GNode h = M.hdr[g];
     if (!h.expanded) return;
     const GEdge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
-    double sum = 0.0; uint32_t best = 0, arg = 0; bool any_n = false;
-    for (uint32_t j = 0; j < h.n_legal; ++j) { const GEdge e = eb[j]; sum += (double)e.n; if (e.n > best) { best = e.n; arg = j; } any_n |= e.n != 0; }
+    // the legal edges are stored in ascending action order, zeros included: a zero count adds 0.0 to the sum (0 ** x == 0 for x > 0)
+    double sum = 0.0; uint32_t best = 0, ties = 0; bool any_n = false;
+    for (uint32_t j = 0; j < h.n_legal; ++j) {
+        const GEdge e = eb[j];
+        if (!one_hot && e.n != 0) sum += temp_weight(e.n, inv_temp);
+        if (e.n > best) { best = e.n; ties = 1; } else if (e.n == best && best > 0) ++ties;
+        any_n |= e.n != 0;
+    }
+    uint32_t pick = 0;
+    if (one_hot && tie_seed != 0 && ties > 1) pick = tie_pick(tie_seed, base + g, ties);
+    uint32_t seen = 0;
     for (uint32_t j = 0; j < h.n_legal; ++j) {
         const GEdge e = eb[j];
         if (visits) visits[(size_t)g * A + e.action] = e.n;
-        if (probs && any_n) probs[(size_t)g * A + e.action] = one_hot ? (j == arg ? 1.0 : 0.0) : (double)e.n / sum;
+        if (probs && any_n) {
+            double p;
+            if (one_hot) { const bool is_max = e.n == best; p = (is_max && seen == pick) ? 1.0 : 0.0; seen += is_max ? 1u : 0u; }
+            else p = e.n != 0 ? temp_weight(e.n, inv_temp) / sum : 0.0;
+            probs[(size_t)g * A + e.action] = p;
+        }
     }
 }
 
@@ -1298,7 +1344,7 @@ int tafl_gmcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_c
     return TAFL_OK;
 }
 
-static int gmcts_dense(tafl_batch* b, uint32_t* visits, double* probs, double temp, int out_is_device) {
+static int gmcts_dense(tafl_batch* b, uint32_t* visits, double* probs, double temp, int out_is_device, uint64_t tie_seed = 0, uint64_t game_id_base = 0) {
     tafl_ctx* c = b->ctx; const uint32_t n = b->n, A = tafl_action_size(c);
     HIPCHK(hipSetDevice(c->device));
     const size_t vb = sizeof(uint32_t) * (size_t)n * A, pb = sizeof(double) * (size_t)n * A;
@@ -1306,7 +1352,7 @@ static int gmcts_dense(tafl_batch* b, uint32_t* visits, double* probs, double te
     if (!out_is_device) { if (visits) { NEED(b->visits, vb); dv = (uint32_t*)b->visits.p; } if (probs) { NEED(b->policy, pb); dp = (double*)b->policy.p; } }
     if (dv) HIPCHK(hipMemsetAsync(dv, 0, vb, c->stream));
     if (dp) HIPCHK(hipMemsetAsync(dp, 0, pb, c->stream));
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_gmcts_root_dense<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->gmem, dv, dp, A, temp == 0.0 ? 1 : 0));
+    DISPATCH_NLW(c, hipLaunchKernelGGL((k_gmcts_root_dense<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->gmem, dv, dp, A, temp == 0.0 ? 1 : 0, temp == 0.0 ? 1.0 : 1.0 / temp, tie_seed, game_id_base));
     HIPCHK(hipGetLastError());
     if (!out_is_device) {
         if (visits) HIPCHK(hipMemcpyAsync(visits, dv, vb, hipMemcpyDeviceToHost, c->stream));
@@ -1319,11 +1365,12 @@ int tafl_gmcts_root_visits(tafl_batch* b, uint32_t* out, int out_is_device) {
     if (!b || !b->g_has || !out) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_root_visits: bad argument");
     return gmcts_dense(b, out, nullptr, 1.0, out_is_device);
 }
-int tafl_gmcts_policy(tafl_batch* b, double temp, double* out, int out_is_device) {
+int tafl_gmcts_policy_ex(tafl_batch* b, double temp, uint64_t tie_seed, uint64_t game_id_base, double* out, int out_is_device) {
     if (!b || !b->g_has || !out) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_policy: bad argument");
-    if (!(temp == 0.0 || temp == 1.0)) return fail(TAFL_ERR_UNSUPPORTED, "tafl_gmcts_policy supports temp 0 and 1");
-    return gmcts_dense(b, nullptr, out, temp, out_is_device);
+    if (!(temp >= 0.0)) return fail(TAFL_ERR_INVALID_ARG, "temp must be >= 0");
+    return gmcts_dense(b, nullptr, out, temp, out_is_device, tie_seed, game_id_base);
 }
+int tafl_gmcts_policy(tafl_batch* b, double temp, double* out, int out_is_device) { return tafl_gmcts_policy_ex(b, temp, 0, 0, out, out_is_device); }
 int tafl_gmcts_get_stats(tafl_batch* b, tafl_gmcts_stats* out) {
     if (!b || !b->g_has || !out) return fail(TAFL_ERR_INVALID_ARG, "tafl_gmcts_get_stats: bad argument");
     tafl_ctx* c = b->ctx;

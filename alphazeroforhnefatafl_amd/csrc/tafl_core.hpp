@@ -683,11 +683,18 @@ struct Engine {
 
     // ---- taflmix32 RNG (build-defined) -----------------------------------------------------------------------
     static TAFL_HD uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
-    static TAFL_HD uint32_t game_key(uint64_t seed, uint64_t game_id) {
+    // game key: 64 bits (two independently mixed words), so that no two of the 524 288 games of BASELINE configs[3] share their whole
+    // stream of simulation keys (a 32-bit key would collide for ~30 pairs); simulation and ply words are 32 bits
+    static TAFL_HD uint64_t game_key(uint64_t seed, uint64_t game_id) {
         const uint32_t h0 = fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) + 0x9E3779B9u));
-        return fmix32(fmix32(h0 ^ (uint32_t)game_id) + (uint32_t)(game_id >> 32));
+        const uint32_t h1 = fmix32((uint32_t)(seed >> 32) ^ fmix32((uint32_t)seed + 0x7F4A7C15u));
+        const uint32_t lo = fmix32(fmix32(h0 ^ (uint32_t)game_id) + (uint32_t)(game_id >> 32));
+        const uint32_t hi = fmix32(fmix32(h1 ^ (uint32_t)(game_id >> 32)) + (uint32_t)game_id * 0x9E3779B1u);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
     }
-    static TAFL_HD uint32_t sim_key(uint32_t gk, uint32_t sim) { return fmix32(gk ^ (sim * 0x9E3779B1u + 0x7F4A7C15u)); }
+    static TAFL_HD uint32_t sim_key(uint64_t gk, uint32_t sim) {
+        return fmix32((uint32_t)gk ^ (sim * 0x9E3779B1u + 0x7F4A7C15u)) ^ fmix32((uint32_t)(gk >> 32) + sim * 0x85EBCA77u + 0x165667B1u);
+    }
     static TAFL_HD uint32_t ply_rand(uint32_t sk, uint32_t ply) { return fmix32(sk + ply * 0x85EBCA77u); }
     static TAFL_HD uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
 

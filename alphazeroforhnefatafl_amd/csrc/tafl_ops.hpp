@@ -104,6 +104,7 @@ struct MctsMem {
     UndoE* ulog_e;               // [g * ulog_cap + i]
     UndoH* ulog_h;               // [g * ulog_cap + i]
     uint32_t G, node_cap, edge_cap, spec_k, ulog_cap;      // spec_k: slots per game that exist (capacity of the arrays above)
+    uint32_t flags;              // TAFL_MCTS_FLAG_* semantics bits of the running search
 };
 
 struct LaneStats {
@@ -273,7 +274,7 @@ struct Ops {
         double v;
         if (kind == 1) {                                        // leaf was expanded by a playout: return -v (mcts.py:100-102)
             NodeHdr* lh = &M.hdr[(size_t)cur * M.G + g];
-            lh->expanded = 1; lh->ns = 0;
+            lh->expanded = 1; lh->ns = (M.flags & TAFL_MCTS_FLAG_FPU_INF) ? 1u : 0u;      // mcts.py:100-101 / mcts.rs:187
             v = -(double)M.rvalue[g];
         } else {
             v = -term_value(M.hdr[(size_t)cur * M.G + g].term); // terminal: return -Es[s] (mcts.py:79-81)
@@ -292,6 +293,8 @@ struct Ops {
     // the action with the highest upper confidence bound (mcts.py:104-119) among the visited children (a prefix of the canonical
     // legal list) and the next unvisited one: returns its index in [0, h.m] (h.m = expand the next unvisited child), -1 if none.
     static TAFL_HD int puct_pick(const MctsMem& M, uint32_t g, const NodeHdr& h, double c_puct) {
+        // first-play urgency of src/mcts.rs:49-51: an unvisited action scores +infinity, the lowest index among them wins
+        if ((M.flags & TAFL_MCTS_FLAG_FPU_INF) && h.m < h.n_legal) return (int)h.m;
         const double p = 1.0 / (double)h.n_legal;
         const double cp = c_puct * p;
         const double sq = sqrt((double)h.ns);
@@ -428,7 +431,7 @@ struct Ops {
         {
             log_hdr(M, g, L, leaf);
             NodeHdr* lh = &M.hdr[(size_t)leaf * M.G + g];
-            lh->expanded = 1; lh->ns = 0;
+            lh->expanded = 1; lh->ns = (M.flags & TAFL_MCTS_FLAG_FPU_INF) ? 1u : 0u;
             if (leaf != 0 && L.ok) {
                 const uint32_t parent = lh->parent;
                 spec_backup(M, g, L, parent, M.hdr[(size_t)parent * M.G + g].edge_base + lh->pslot, -assumed);

@@ -9,6 +9,7 @@ All compute runs in HIP kernels through the C-ABI (include/taflhip.h); there is 
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 from . import abi
 from ._lib import check, lib
@@ -27,13 +28,21 @@ class BatchedGameLogic:
         self.word_bits = word_bits or abi.word_bits_for(side_len)
         self.device = device
         self._c_rules = rules.to_c()
+        self._batches = []               # weak references to the GameBatch objects created on this context
         self._h = C.c_void_p()
         check(lib().tafl_ctx_create(C.byref(self._c_rules), side_len, self.word_bits, device,
                                     C.c_void_p(stream) if stream else None, C.byref(self._h)))
 
     def close(self):
+        """Destroys the context; batches created from it that are still open are closed first (the library refuses to destroy a
+        context with live batches)."""
         if self._h:
-            lib().tafl_ctx_destroy(self._h)
+            for ref in list(self._batches):
+                b = ref()
+                if b is not None:
+                    b.close()
+            self._batches.clear()
+            check(lib().tafl_ctx_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -86,6 +95,7 @@ class GameBatch:
         self.n = n_games
         self._h = C.c_void_p()
         check(lib().tafl_batch_create(logic._h, n_games, C.byref(self._h)))
+        logic._batches.append(weakref.ref(self))
 
     def close(self):
         if self._h:
@@ -204,13 +214,14 @@ class GameBatch:
         check(lib().tafl_encode_boards(self._h, C.cast(out, C.c_void_p), 0))
         return out
 
-    def mcts_policy_device(self, temp: float = 1.0, out_device_ptr: int | None = None):
-        """src/mcts.py:40-53 written by a kernel (temp 0 or 1); float64 [n, action_size]."""
+    def mcts_policy_device(self, temp: float = 1.0, out_device_ptr: int | None = None, tie_seed: int = 0, game_id_base: int = 0):
+        """src/mcts.py:40-53 written by a kernel, any temp >= 0; float64 [n, action_size].  temp == 0: one-hot on the first maximum, or
+        with tie_seed != 0 on the seeded choice among the maxima (the reference draws it with np.random.choice)."""
         if out_device_ptr is not None:
-            check(lib().tafl_mcts_policy_device(self._h, temp, C.c_void_p(out_device_ptr), 1))
+            check(lib().tafl_mcts_policy_device_ex(self._h, temp, tie_seed, game_id_base, C.c_void_p(out_device_ptr), 1))
             return None
         out = (C.c_double * (self.n * self.logic.action_size))()
-        check(lib().tafl_mcts_policy_device(self._h, temp, C.cast(out, C.c_void_p), 0))
+        check(lib().tafl_mcts_policy_device_ex(self._h, temp, tie_seed, game_id_base, C.cast(out, C.c_void_p), 0))
         return out
 
     # -- guided MCTS: the caller's network is nnet.predict (src/mcts.py:85) --------------------------------------------
@@ -251,12 +262,12 @@ class GameBatch:
         check(lib().tafl_gmcts_root_visits(self._h, C.cast(out, C.c_void_p), 0))
         return out
 
-    def gmcts_policy(self, temp: float = 1.0, out_device_ptr: int | None = None):
+    def gmcts_policy(self, temp: float = 1.0, out_device_ptr: int | None = None, tie_seed: int = 0, game_id_base: int = 0):
         if out_device_ptr is not None:
-            check(lib().tafl_gmcts_policy(self._h, temp, C.c_void_p(out_device_ptr), 1))
+            check(lib().tafl_gmcts_policy_ex(self._h, temp, tie_seed, game_id_base, C.c_void_p(out_device_ptr), 1))
             return None
         out = (C.c_double * (self.n * self.logic.action_size))()
-        check(lib().tafl_gmcts_policy(self._h, temp, C.cast(out, C.c_void_p), 0))
+        check(lib().tafl_gmcts_policy_ex(self._h, temp, tie_seed, game_id_base, C.cast(out, C.c_void_p), 0))
         return out
 
     def gmcts_stats(self) -> TaflGmctsStats:

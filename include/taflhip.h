@@ -197,6 +197,13 @@ typedef struct tafl_mcts_params {
     uint32_t sim_offset;       /* first simulation index used in the RNG key (normally 0) */
     uint32_t flags;            /* TAFL_MCTS_FLAG_* | tuning fields; 0 = src/mcts.py semantics, default pipeline */
 } tafl_mcts_params;
+/* semantics bits of tafl_mcts_params.flags.
+ *   TAFL_MCTS_FLAG_FPU_INF  first-play urgency of the reference's Rust sketch, src/mcts.rs: an action that was never taken scores
+ *     f64::INFINITY in the selection (mcts.rs:49-51), so every legal child of a node is expanded before any child is revisited, and a
+ *     newly expanded node starts with visits = 1.0 instead of 0 (mcts.rs:187).  Ties keep src/mcts.py's rule (first maximum = lowest
+ *     action index; the sketch does not compile and leaves the order of `valid_actions` undefined).  Everything else is src/mcts.py.
+ *     This mode is pinned by the oracle only (no reference implementation can run it). */
+#define TAFL_MCTS_FLAG_FPU_INF 0x1u
 /* tuning fields of tafl_mcts_params.flags: they choose HOW the same search is executed and never change its results
  * (tests/test_gpu_parity.py::test_mcts_pipelines_agree).
  *   bits 4-7   pipeline: 0 default (two kernels per round: tree phase + playouts over a dense work list), 1 fused (one kernel per
@@ -213,7 +220,7 @@ typedef struct tafl_mcts_params {
 #define TAFL_MCTS_TUNE_PARTS_OF(f) (((f) >> 12) & 15u)
 #define TAFL_MCTS_TUNE_PIPELINE_OF(f) (((f) >> 4) & 15u)
 #define TAFL_MCTS_TUNE_SLOTS_OF(f) (((f) >> 8) & 15u)
-#define TAFL_MCTS_FLAGS_KNOWN 0x0000FFF0u
+#define TAFL_MCTS_FLAGS_KNOWN 0x0000FFF1u
 
 typedef struct tafl_mcts_stats {
     uint64_t sims;             /* simulations executed (all games) */
@@ -330,12 +337,16 @@ int tafl_mcts_play_best(tafl_batch* b, tafl_play* out_plays, tafl_effects* out_e
 /* ---- training-tensor writers (the step right after the hot path) ------------------------------
  * tafl_encode_boards: board_to_matrix (game/main.rs:55-83) for every game: uint8 [n * side_len * side_len], row-major;
  *   corner tiles 20, throne 30, soldier +1, king +5 (no side distinction, as in the reference).
- * tafl_mcts_policy_device: the probs of src/mcts.py:40-53 written by a kernel, for temp == 1 (counts / sum, exact) or
- *   temp == 0 (one-hot on the first maximum); float64 [n * tafl_action_size].
+ * tafl_mcts_policy_device: the probs of src/mcts.py:40-53 written by a kernel, for any temp >= 0 (temp == 1: counts / sum, exact;
+ *   temp == 0: one-hot on the first maximum); float64 [n * tafl_action_size].
  * `out` may be a host pointer (out_is_device = 0) or a device pointer of this ctx's device (out_is_device = 1, e.g. a
  * torch tensor's data_ptr): the second form never crosses PCIe. */
 int tafl_encode_boards(tafl_batch* b, uint8_t* out, int out_is_device);
 int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_device);
+/* the same with the choices mcts.py:44-45 leaves to np.random: temp == 0 puts the 1 on the (r mod ties)-th maximum in ascending action
+ * order, r = taflmix32 word of (tie_seed, game_id_base + game); tie_seed == 0 = the first maximum.  Any temp >= 0: counts ** (1 / temp) is the
+ * device math library's float64 pow (exact for temp == 1; within 2 ulp of the host's pow otherwise, tests/test_gpu_parity.py). */
+int tafl_mcts_policy_device_ex(tafl_batch* b, double temp, uint64_t tie_seed, uint64_t game_id_base, double* out, int out_is_device);
 
 /* ---- guided MCTS: src/mcts.py:55-136 with the CALLER's network as nnet.predict (mcts.py:85), SURVEY.md section 8f rank 3 ---
  * Lock-step over the batch: each tafl_gmcts_step (i) expands every waiting leaf with the priors / value the caller computed
@@ -361,6 +372,7 @@ int tafl_gmcts_leaves(tafl_batch* b, uint8_t* boards, uint8_t* sides, uint8_t* w
 int tafl_gmcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_children, uint32_t* out_n);
 int tafl_gmcts_root_visits(tafl_batch* b, uint32_t* out, int out_is_device);
 int tafl_gmcts_policy(tafl_batch* b, double temp, double* out, int out_is_device);
+int tafl_gmcts_policy_ex(tafl_batch* b, double temp, uint64_t tie_seed, uint64_t game_id_base, double* out, int out_is_device);
 int tafl_gmcts_get_stats(tafl_batch* b, tafl_gmcts_stats* out);
 
 /* ---- replay buffer on disk: write_to_file, game/main.rs:86-132 ------------------------

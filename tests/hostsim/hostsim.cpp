@@ -74,7 +74,7 @@ struct Host {
         using IO = StateIO<NL>;
         // same host loop as tafl_mcts_run's two-kernel pipeline: g_spec_k slots exist per game, the search is planned for
         // ceil(n_sims / g_spec_target) rounds (g_spec_target = 0: every game issues as many slots as it may, every round)
-        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k; M.ulog_cap = g_spec_k > 1 ? 64 : 0;
+        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k; M.ulog_cap = g_spec_k > 1 ? 64 : 0; M.flags = p->flags & TAFL_MCTS_FLAG_FPU_INF;
         std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS), sst((size_t)M.spec_k * G * IO::QUADS);
         std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
         std::vector<Edge> edges((size_t)M.edge_cap * G);

@@ -571,3 +571,122 @@ def test_mcts_play_best_is_best_play_plus_do_play():
                 assert pu.effects_tuple(oeff[g]) == pu.effects_tuple(eff[g]), (move, g)
         # games without a play were not touched by the device; undo the oracle's rejected empty play bookkeeping (none: rejected plays change nothing)
         assert pu.states_equal(cur, ostates, G), pu.first_state_diff(cur, ostates, G)
+
+
+@pytest.mark.parametrize("name,G,sims", [("copenhagen11", 96, 150), ("brandubh7", 128, 120), ("copenhagen13", 40, 60)])
+def test_mcts_first_play_urgency_flag_vs_oracle(name, G, sims):
+    """TAFL_MCTS_FLAG_FPU_INF (src/mcts.rs:49-51,187): unvisited actions score +inf, new nodes start with visits 1.  The sketch cannot
+    run, so the mode is pinned by the oracle's twin only ("parity unpinned" against the reference); GPU == oracle bit for bit."""
+    rules, fen, wb, n, lg = _mk(name)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 7) % 33 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 4, plies, 11)
+    K = 24                                     # oracle on the first K games (it is slow), the GPU on all of them
+    p = TaflMctsParams(sims, 256, 1.0, 6, 0, abi.MCTS_FLAG_FPU_INF)
+    ok, on, _ = orc.batch_mcts(lg, states, K, wb, p, 11)
+    results = []
+    for tune in (0, abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 2), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 8, 1)):
+        b = gpu_batch(rules, n, wb, states, G)
+        b.mcts_run(sims, 1.0, 6, 256, game_id_base=11, flags=abi.MCTS_FLAG_FPU_INF | tune)
+        gk, gn = b.mcts_root_children(256)
+        st = b.mcts_stats()
+        assert st.sims == G * sims and st.faults == 0
+        results.append([(gk[g * 256 + j].action, gk[g * 256 + j].visits, float(gk[g * 256 + j].q).hex()) for g in range(G) for j in range(gn[g])])
+        for g in range(K):
+            assert on[g] == gn[g]
+            for j in range(on[g]):
+                x, y = ok[g * 256 + j], gk[g * 256 + j]
+                assert (x.action, x.visits, float(x.q).hex()) == (y.action, y.visits, float(y.q).hex()), (name, g, j)
+        b.close()
+    assert results[0] == results[1] == results[2]
+    # and it is a different search from the default one
+    b = gpu_batch(rules, n, wb, states, G)
+    b.mcts_run(sims, 1.0, 6, 256, game_id_base=11)
+    gk, gn = b.mcts_root_children(256)
+    assert results[0] != [(gk[g * 256 + j].action, gk[g * 256 + j].visits, float(gk[g * 256 + j].q).hex()) for g in range(G) for j in range(gn[g])]
+
+
+def _tafl_fmix32(h):
+    h &= 0xFFFFFFFF; h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF; h ^= h >> 16
+    return h
+
+
+def _tie_pick(seed, gid, ties):
+    """taflmix32 word of (tie_seed, global game id) -> index among the maxima (include/taflhip.h: tafl_mcts_policy_device_ex)."""
+    f = _tafl_fmix32
+    slo, shi, glo, ghi = seed & 0xFFFFFFFF, seed >> 32, gid & 0xFFFFFFFF, gid >> 32
+    h0 = f(slo ^ f(shi + 0x9E3779B9)); h1 = f(shi ^ f(slo + 0x7F4A7C15))
+    lo = f(f(h0 ^ glo) + ghi); hi = f(f(h1 ^ ghi) + glo * 0x9E3779B1)
+    h = f(lo ^ f(hi + 0x7A1E5EED))
+    return (h * ties) >> 32
+
+
+def test_policy_for_any_temperature_and_seeded_tie_break():
+    """getActionProb (src/mcts.py:40-53) on the device: counts ** (1 / temp) / sum for any temp > 0 (device pow: compared with the
+    host's libm within 4 ulp, exact for temp == 1 and for integer exponents), and temp == 0 with the np.random.choice among the maxima
+    replaced by a seeded, sharding-independent draw (tie_seed; 0 = the first maximum)."""
+    import math
+    rules, fen, wb, n, lg = _mk("copenhagen11")
+    G, sims, base = 96, 40, 1000
+    b = gpu_logic(rules, n, wb).new_batch(G, fen)
+    b.mcts_run(sims, 1.0, 5, 128, game_id_base=base)
+    A = b.logic.action_size
+    visits = b.mcts_root_visits()
+    for temp in (1.0, 0.5, 0.25, 2.0, 0.7, 1.3):
+        dev = b.mcts_policy_device(temp)
+        host = b.mcts_policy(temp)                      # host: libm pow on the downloaded counts, same operation order
+        exact = temp in (1.0, 0.5, 0.25)
+        for g in range(G):
+            cnt = visits[g * A:(g + 1) * A]
+            ex = 1.0 / temp
+            w = [float(c) ** ex for c in cnt]           # Python: x ** (1. / temp)
+            ssum = float(sum(w))
+            for a in range(A):
+                d, h = dev[g * A + a], host[g * A + a]
+                want = w[a] / ssum
+                if exact:
+                    assert d == want == h, (temp, g, a)
+                else:
+                    assert h == want
+                    assert d == want or abs(d - want) <= 4 * math.ulp(want), (temp, g, a, d, want)
+    # temp == 0: one-hot on a maximum
+    first = b.mcts_policy_device(0.0)
+    assert bytes(first) == bytes(b.mcts_policy(0.0))
+    seeded = b.mcts_policy_device(0.0, tie_seed=77, game_id_base=base)
+    moved = 0
+    for g in range(G):
+        cnt = visits[g * A:(g + 1) * A]
+        mx = max(cnt)
+        maxima = [a for a in range(A) if cnt[a] == mx]
+        row = seeded[g * A:(g + 1) * A]
+        assert sum(row) == 1.0 and sorted(set(row)) == [0.0, 1.0]
+        want = maxima[_tie_pick(77, base + g, len(maxima))] if len(maxima) > 1 else maxima[0]
+        assert row[want] == 1.0, (g, maxima, want)
+        assert first[g * A + maxima[0]] == 1.0
+        moved += want != maxima[0]
+    assert moved > 0                                      # ties exist at 40 simulations and the seed moves some of them
+    # the same draw from a shard of the batch with its own base
+    half = gpu_logic(rules, n, wb).new_batch(G // 2, fen)
+    half.mcts_run(sims, 1.0, 5, 128, game_id_base=base + G // 2)
+    hs = half.mcts_policy_device(0.0, tie_seed=77, game_id_base=base + G // 2)
+    assert list(hs) == list(seeded[(G // 2) * A:])
+
+
+def test_context_refuses_to_die_before_its_batches():
+    from alphazeroforhnefatafl_amd._lib import lib
+    from alphazeroforhnefatafl_amd.engine import BatchedGameLogic
+    rules, fen, wb, n, lg = _mk("brandubh7")
+    logic = BatchedGameLogic(rules, n, wb)
+    b = logic.new_batch(10, fen)
+    assert lib().tafl_ctx_destroy(logic._h) != 0          # library level: refused while a batch is alive
+    counts, _ = b.iter_plays(want_masks=False)            # the batch still works
+    assert counts[0] == 40
+    logic.close()                                         # host mirror: closes its batches first
+    assert not b._h and not logic._h
+    # range checks of upload / download do not wrap
+    logic2 = BatchedGameLogic(rules, n, wb)
+    b2 = logic2.new_batch(4, fen)
+    st = b2.download()
+    assert lib().tafl_batch_upload(b2._h, st, 0xFFFFFFFF, 2) != 0
+    assert lib().tafl_batch_download(b2._h, st, 3, 0xFFFFFFFE) != 0
+    logic2.close()

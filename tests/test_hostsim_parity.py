@@ -215,3 +215,40 @@ def test_mcts_with_a_full_device_round_capacity(k, target, capacity):
     for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
         assert getattr(ostats, f) == getattr(hstats, f), f
     assert list(ostats.reason_hist) == list(hstats.reason_hist)
+
+
+@pytest.mark.parametrize("name,sims,k", [("brandubh7", 150, 4), ("copenhagen11", 140, 8), ("tablut9", 120, 1)])
+def test_mcts_first_play_urgency_flag(name, sims, k):
+    """TAFL_MCTS_FLAG_FPU_INF (the src/mcts.rs sketch: unvisited actions score +inf, mcts.rs:49-51; a new node starts with visits 1,
+    mcts.rs:187): the device functions against the oracle's twin, bit for bit.  The Rust sketch cannot be built or run, so this mode is
+    pinned by the oracle alone.  Every root child is expanded before any is revisited."""
+    from tests.hostsim import hostsim
+    rules, fen, wb = pu.CONFIGS[name]
+    n = abi.fen_side_len(fen)
+    G = 6
+    lg, hs = orc.GameLogic(rules, n), HostSim(rules, n, wb)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 4) % 13 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 3, plies, 2)
+    p = TaflMctsParams(sims, 200, 1.0, 8, 0, abi.MCTS_FLAG_FPU_INF)
+    p0 = TaflMctsParams(sims, 200, 1.0, 8, 0, 0)
+    ok, on, ostats = orc.batch_mcts(lg, states, G, wb, p, 2)
+    ok0, on0, _ = orc.batch_mcts(lg, states, G, wb, p0, 2)
+    hostsim.set_spec_k(k, 0, 0)
+    try:
+        hk, hn, hstats = hs.mcts(states, G, p, 2)
+    finally:
+        hostsim.set_spec_k(4, 0, 0)
+    assert list(on) == list(hn)
+    counts, _ = orc.batch_movegen(lg, states, G, wb, want_masks=False)
+    differs = False
+    for g in range(G):
+        if sims > counts[g] and counts[g] > 0:
+            assert on[g] == counts[g], (g, on[g], counts[g])          # breadth first: every legal play of the root was tried
+        for j in range(on[g]):
+            a, b = ok[g * 256 + j], hk[g * 256 + j]
+            assert (a.action, a.visits, float(a.q).hex()) == (b.action, b.visits, float(b.q).hex()), (g, j)
+        differs |= [(ok[g * 256 + j].action, ok[g * 256 + j].visits) for j in range(on[g])] != [(ok0[g * 256 + j].action, ok0[g * 256 + j].visits) for j in range(on0[g])]
+    assert differs
+    for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+        assert getattr(ostats, f) == getattr(hstats, f), f

@@ -43,7 +43,7 @@ def parse_kernel(path, name):
     lines = open(path).read().split("\n")
     start = None
     for i, l in enumerate(lines):
-        if re.match(r"^_Z\w*:", l) and name in l.split(":")[0]:
+        if re.match(r"^[A-Za-z_]\w*:", l) and name in l.split(":")[0]:
             start = i
             break
     if start is None:
