@@ -65,23 +65,39 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_movegen(Consts<NL> C, const Quad
     counts[g] = Ops<NL, W>::movegen(st, C, nullptr);
 }
 
-// counts + dense action masks: each lane builds its game's mask in LDS (ds_or, no global read-modify-write), then the
-// workgroup streams the 64 masks out as one contiguous block (64 x mask_words uint32, fully coalesced).
+// counts + dense action masks.  A workgroup of four waves serves 64 games: lane = game, WAVE = move direction (V+, V-, H+, H-), each
+// wave generating only its own direction's reach set and writing one bit field per piece (Ops::movegen_fields), so the direction is
+// wave-uniform (no divergence) and the work of a position is spread over four waves.  The masks are assembled in LDS (ds_or, odd row
+// stride: no bank conflicts) and streamed out as one contiguous block per workgroup (64 x mask_words uint32, fully coalesced).
+#define TAFL_MG_WAVES 4
 template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_movegen_masks(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t* counts, uint32_t* masks, uint32_t mw) {
-    extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw]
-    const uint32_t g0 = blockIdx.x * TAFL_BLOCK, g = g0 + threadIdx.x;
-    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * mw; i += TAFL_BLOCK) lds_masks[i] = 0;
+__device__ __forceinline__ uint32_t movegen_wave(const DState<NL>& st, uint32_t dir, const Consts<NL>& C, uint32_t* row) {      // dir is wave-uniform
+    switch (dir) {
+        case 0: return Ops<NL, W>::template movegen_fields<DIR_VP>(st, C, row);
+        case 1: return Ops<NL, W>::template movegen_fields<DIR_VM>(st, C, row);
+        case 2: return Ops<NL, W>::template movegen_fields<DIR_HP>(st, C, row);
+        default: return Ops<NL, W>::template movegen_fields<DIR_HM>(st, C, row);
+    }
+}
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK * TAFL_MG_WAVES) void k_movegen_masks(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t* counts, uint32_t* masks, uint32_t mw) {
+    extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw | 1] masks, then [TAFL_BLOCK] counts
+    const uint32_t ldw = mw | 1u, lane = threadIdx.x & 63u, dir = threadIdx.x >> 6;
+    const uint32_t g0 = blockIdx.x * TAFL_BLOCK, g = g0 + lane;
+    uint32_t* lds_cnt = lds_masks + TAFL_BLOCK * ldw;
+    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * (ldw + 1u); i += TAFL_BLOCK * TAFL_MG_WAVES) lds_masks[i] = 0;
     __syncthreads();
     if (g < n) {
         DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
-        const uint32_t c = Ops<NL, W>::movegen(st, C, lds_masks + (size_t)threadIdx.x * mw);
-        if (counts) counts[g] = c;
+        const uint32_t c = movegen_wave<NL, W>(st, dir, C, lds_masks + (size_t)lane * ldw);
+        if (c) atomicAdd(&lds_cnt[lane], c);
     }
     __syncthreads();
+    if (dir == 0 && g < n && counts) counts[g] = lds_cnt[lane];
     const uint32_t games = (n - g0) < TAFL_BLOCK ? (n - g0) : TAFL_BLOCK;
     uint32_t* dst = masks + (size_t)g0 * mw;
-    for (uint32_t i = threadIdx.x; i < games * mw; i += TAFL_BLOCK) dst[i] = lds_masks[i];
+    for (uint32_t gi = dir; gi < games; gi += TAFL_MG_WAVES)                                  // one game per wave and pass: 304 contiguous bytes
+        for (uint32_t w = lane; w < mw; w += TAFL_BLOCK) dst[(size_t)gi * mw + w] = lds_masks[(size_t)gi * ldw + w];
 }
 
 template <int NL, int W>
@@ -103,16 +119,26 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_step(Consts<NL> C, Quad* soa, ui
     if (eff) eff[g] = e;
 }
 
+// game i plays its (rank mod count)-th legal play in canonical order: the dense legal mask is built in LDS by four direction waves as in
+// k_movegen_masks, then the first wave (lane = game) finds the k-th set bit and applies the play
 template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_step_kth(Consts<NL> C, Quad* soa, uint32_t n, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff, uint32_t mw) {
-    extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw]: each game's dense legal mask, private to its lane
-    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
-    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * mw; i += TAFL_BLOCK) lds_masks[i] = 0;
+__global__ __launch_bounds__(TAFL_BLOCK * TAFL_MG_WAVES) void k_step_kth(Consts<NL> C, Quad* soa, uint32_t n, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff, uint32_t mw) {
+    extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw | 1] masks, then [TAFL_BLOCK] counts
+    const uint32_t ldw = mw | 1u, lane = threadIdx.x & 63u, dir = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + lane;
+    uint32_t* lds_cnt = lds_masks + TAFL_BLOCK * ldw;
+    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * (ldw + 1u); i += TAFL_BLOCK * TAFL_MG_WAVES) lds_masks[i] = 0;
     __syncthreads();
-    if (g >= n) return;
-    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    DState<NL> st;
+    if (g < n) {
+        StateIO<NL>::load_soa(soa, n, g, st);
+        const uint32_t c = movegen_wave<NL, W>(st, dir, C, lds_masks + (size_t)lane * ldw);
+        if (c) atomicAdd(&lds_cnt[lane], c);
+    }
+    __syncthreads();
+    if (dir != 0 || g >= n) return;
     tafl_effects e; tafl_play p;
-    Ops<NL, W>::step_kth(st, ranks[g], C, &p, &e, lds_masks + (size_t)threadIdx.x * mw, mw);
+    Ops<NL, W>::step_kth_finish(st, ranks[g], lds_cnt[lane], C, &p, &e, lds_masks + (size_t)lane * ldw, mw);
     StateIO<NL>::store_soa(soa, n, g, st);
     if (eff) eff[g] = e;
     if (out_plays) out_plays[g] = p;
@@ -735,7 +761,7 @@ int tafl_movegen(tafl_batch* b, uint32_t* out_counts, uint32_t* out_masks) {
     {
         SpanGuard sg(c, KC_MOVEGEN);
         if (out_masks) {
-            DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen_masks<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), TAFL_BLOCK * mw * sizeof(uint32_t), c->stream,
+            DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen_masks<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK * TAFL_MG_WAVES), TAFL_BLOCK * ((mw | 1u) + 1u) * sizeof(uint32_t), c->stream,
                                                CC, b->soa, n, (uint32_t*)b->counts.p, (uint32_t*)b->masks.p, mw));
         } else {
             DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, (uint32_t*)b->counts.p));
@@ -790,7 +816,7 @@ int tafl_step_kth(tafl_batch* b, const uint32_t* ranks, tafl_play* out_plays, ta
     HIPCHK(hipMemcpyAsync(b->ranks.p, ranks, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
     {
         SpanGuard sg(c, KC_STEP);
-        DISPATCH_NLW(c, hipLaunchKernelGGL((k_step_kth<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), TAFL_BLOCK * tafl_action_mask_words(c) * sizeof(uint32_t), c->stream,
+        DISPATCH_NLW(c, hipLaunchKernelGGL((k_step_kth<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK * TAFL_MG_WAVES), TAFL_BLOCK * ((tafl_action_mask_words(c) | 1u) + 1u) * sizeof(uint32_t), c->stream,
                                            CC, b->soa, n, (const uint32_t*)b->ranks.p, out_plays ? (tafl_play*)b->out_plays.p : nullptr,
                                            out_effects ? (tafl_effects*)b->effects.p : nullptr, tafl_action_mask_words(c)));
     }
@@ -891,9 +917,12 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     const uint32_t pipe = TAFL_MCTS_TUNE_PIPELINE_OF(p->flags);
     uint32_t slots = TAFL_MCTS_TUNE_SLOTS_OF(p->flags);
     if (pipe > TAFL_MCTS_PIPELINE_TWO_KERNEL) return fail(TAFL_ERR_UNSUPPORTED, "tafl_mcts_params.flags: unknown pipeline");
-    // default: the two-kernel pipeline; boards up to 9x9 have playouts so short (Brandubh: ~65 plies) that the per-round launches and the
+    // default: the two-kernel pipeline; 7x7 boards have playouts so short (Brandubh: ~65 plies) that the per-round launches and the
     // exposed tree phase cost more than the fused kernel's two waves per SIMD (measured: 92 M vs 31 M sims/s on 7x7)
-    const bool fused = pipe == TAFL_MCTS_PIPELINE_FUSED || (pipe == TAFL_MCTS_PIPELINE_DEFAULT && c->n <= 9 && slots <= 2);
+    // The fused kernel is built for 64-bit boards only (7x7): on wider boards its tree phase does not fit the register file beside the
+    // playout loop (256 VGPRs and spills) and the two-kernel pipeline is faster anyway (13x13: 44.9 M vs 37.4 M sims/s).
+    if (pipe == TAFL_MCTS_PIPELINE_FUSED && c->nl != 2) return fail(TAFL_ERR_UNSUPPORTED, "the fused pipeline exists for 64-bit boards (word_bits 64) only");
+    const bool fused = pipe == TAFL_MCTS_PIPELINE_FUSED || (pipe == TAFL_MCTS_PIPELINE_DEFAULT && c->nl == 2 && slots <= 2);
     if (slots == 0) {
         // enough playouts in flight for ~4 waves per SIMD (1024 SIMDs x 64 lanes): 4 slots per game at 65 536 games
         slots = fused ? 2u : (uint32_t)((4ull * 65536ull + n - 1) / n);
@@ -914,10 +943,14 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
             const uint32_t rounds = chunk_len < rounds_left ? chunk_len : rounds_left;
             {
                 SpanGuard sg(c, KC_MCTS_ROLLOUT);
-                if (slots == 2) { DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct,
-                                                                      p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st)); }
-                else { DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct,
-                                                           p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st)); }
+                constexpr int NL = 2, W = 7; const Consts<2>& CC = c->c2;
+                if (c->preset == PRESET_BRANDUBH7) {
+                    if (slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st);
+                    else hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st);
+                } else {
+                    if (slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st);
+                    else hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st);
+                }
             }
             rounds_left -= rounds;
             if (chunk_len < 16) chunk_len *= 2;

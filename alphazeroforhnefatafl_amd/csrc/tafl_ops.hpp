@@ -148,24 +148,103 @@ struct Ops {
         return (r * C.n + c) * 2u * nm + slot;
     }
 
-    // tafl_movegen: count + dense action mask (mask may be null; it must be zero-initialised by the caller)
-    static TAFL_HD uint32_t movegen(const S& st, const K& C, uint32_t* mask) {
-        Moves<NL> mv;
-        E::movegen(st, st.flags & TAFL_F_SIDE, C, mv);
-        if (mask) {
-            TAFL_UNROLL
-            for (int d = 0; d < 4; ++d) {
-                Bits<NL> r = mv.reach[d];
-                while (any(r)) {
-                    const uint32_t to = lsb(r);
-                    r = andn(r, bit_at<NL>(to));
-                    const Move m = E::resolve(st, (uint32_t)d, to, C);
-                    const uint32_t a = action_of(m, C);
-                    if (a < C.n * C.n * 2u * (C.n - 1)) mask[a >> 5] |= 1u << (a & 31);   // never write outside the game's mask
-                }
+    // ---- tafl_movegen: count + dense action mask ------------------------------------------------------------------------------
+    // The dense mask holds, per source tile, one field of 2(n-1) bits: [V+ distances 1..n-1-r][V- 1..r][H+ 1..n-1-c][H- 1..c]
+    // (include/taflhip.h).  It is written one DIRECTION at a time and, inside a direction, one PIECE at a time: all plays of a piece in
+    // one direction are the tiles of that direction's reach set between the piece and the first occupied tile behind them (a tile of the
+    // reach set belongs to the nearest piece behind it), i.e. one small bit field per piece instead of one resolve per destination.
+    // On the device four waves (one per direction) work on the same 64 games side by side and OR their fields into LDS.
+
+    // reach set of the side to move restricted to one direction (Engine::movegen is the four of them)
+    template <int DIR> static TAFL_HD Bits<NL> movegen_dir(const S& st, uint32_t side, const K& C) {
+        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return bz<NL>();            // logic.rs:165-167
+        const Bits<NL> occ = st.att | st.def, empty = andn(C.board, occ);
+        auto cls = [&](const Bits<NL>& gen, int c) {
+            return E::template ray_reach<DIR>(gen, andn(empty, C.pass_forbid[c]), andn(empty, C.land_forbid[c]), C.slow[c] != 0, C);
+        };
+        if (side == 0) return cls(st.att & C.board, CLS_ATT);
+        if (C.king_like_soldier) return cls(st.def & C.board, CLS_DEF);
+        const Bits<NL> kb = E::king_bit(st, C);
+        Bits<NL> r = cls(andn(st.def & C.board, kb), CLS_DEF);
+        if (any(kb)) r |= cls(kb, CLS_KING);
+        return r;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TAFL_MASK_OR(p, v) atomicOr((p), (v))          /* four waves write one game's mask */
+#else
+#define TAFL_MASK_OR(p, v) (*(p) |= (v))
+#endif
+    // row `R0` (compile time) of a board word as an n-bit value
+    template <int R0> static TAFL_HD uint32_t rowbits(const Bits<NL>& a) {
+        constexpr int pos = R0 * W, wi = pos >> 5, off = pos & 31;
+        uint32_t v = a.w[wi] >> off;
+        if constexpr (off + W > 32 && wi + 1 < NL) v |= a.w[wi + 1] << (32 - off);
+        return v & ((1u << W) - 1u);
+    }
+    // the position mirrored at the main diagonal (tile (r, c) -> (c, r)): a vertical play of `st` is a horizontal play of the mirror image,
+    // and every rule mask (board, corners, throne and what derives from them) is symmetric, so the same row code serves both axes
+    static TAFL_HD void transpose_state(const S& st, S& t) {
+        t = st;
+        t.att = bz<NL>(); t.def = bz<NL>();
+        Bits<NL> p = st.att;
+        while (any(p)) { const uint32_t i = lsb(p); p = andn(p, bit_at<NL>(i)); t.att |= bit_at<NL>(Fast<NL, W>::n_to_t(i)); }
+        p = st.def;
+        while (any(p)) { const uint32_t i = lsb(p); p = andn(p, bit_at<NL>(i)); t.def |= bit_at<NL>(Fast<NL, W>::n_to_t(i)); }
+        t.flags = (st.flags & ~0x00FF0000u) | (TAFL_F_KCOL(st.flags) << 16) | (TAFL_F_KROW(st.flags) << 20);
+    }
+    // one row of horizontal plays: every piece of `mine` in row R0 gets the field of its plays to the right (PLUS) or left, cut out of the
+    // row of the reach set between the piece and the first occupied tile behind it.  TR: the position is the mirror image (vertical plays).
+    template <int R0, bool PLUS, bool TR> static TAFL_HD void row_fields(const Bits<NL>& R, const Bits<NL>& occ, const Bits<NL>& mine, uint32_t n, uint32_t* row) {
+        const uint32_t rowR = rowbits<R0>(R);
+        if (rowR == 0) return;
+        const uint32_t rowO = rowbits<R0>(occ), nm = n - 1u;
+        uint32_t m = rowbits<R0>(mine);
+        while (m) {
+            const uint32_t c = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            uint32_t field;
+            if constexpr (PLUS) {
+                const uint32_t lm = (1u << (nm - c)) - 1u;
+                const uint32_t bl = (rowO >> (c + 1u)) & lm;                     // pieces further along the row
+                field = (rowR >> (c + 1u)) & ((bl & (0u - bl)) - 1u) & lm;       // reach tiles before the first of them
+            } else {
+                if (c == 0) continue;
+                const uint32_t lm = (1u << c) - 1u, sh = 32u - c;
+                const uint32_t bl = bitrev32((rowO & lm) << sh);                 // the row segment before the piece, nearest tile first
+                field = bitrev32((rowR & lm) << sh) & ((bl & (0u - bl)) - 1u) & lm;
             }
+            if (field == 0) continue;
+            // source tile (r, c) of the ORIGINAL position and the first slot of this direction inside its 2(n-1)-bit field
+            const uint32_t r_o = TR ? c : (uint32_t)R0, c_o = TR ? (uint32_t)R0 : c;
+            const uint32_t slot0 = TR ? (PLUS ? 0u : nm - r_o) : (PLUS ? nm : nm + (nm - c_o));
+            const uint32_t a0 = mul24(mul24(r_o, n) + c_o, 2u * nm) + slot0, w = a0 >> 5, sh2 = a0 & 31u;
+            TAFL_MASK_OR(&row[w], field << sh2);
+            if (sh2 != 0 && (field >> (32u - sh2)) != 0) TAFL_MASK_OR(&row[w + 1u], field >> (32u - sh2));
         }
-        return mv.total;
+    }
+    template <int R0, bool PLUS, bool TR> static TAFL_HD void all_row_fields(const Bits<NL>& R, const Bits<NL>& occ, const Bits<NL>& mine, uint32_t n, uint32_t* row) {
+        if constexpr (R0 < W) {
+            if ((uint32_t)R0 < n) row_fields<R0, PLUS, TR>(R, occ, mine, n, row);
+            all_row_fields<R0 + 1, PLUS, TR>(R, occ, mine, n, row);
+        }
+    }
+    // plays of the side to move in direction DIR: returns their number and, if `row` is not null, ORs them into the game's dense mask
+    template <int DIR> static TAFL_HD uint32_t movegen_fields(const S& st, const K& C, uint32_t* row) {
+        const uint32_t side = st.flags & TAFL_F_SIDE;
+        if (!row) return popc(movegen_dir<DIR>(st, side, C));
+        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return 0;
+        constexpr bool TR = DIR == DIR_VP || DIR == DIR_VM, PLUS = DIR == DIR_VP || DIR == DIR_HP;
+        S t;
+        if constexpr (TR) transpose_state(st, t); else t = st;
+        const Bits<NL> R = movegen_dir<PLUS ? DIR_HP : DIR_HM>(t, side, C);
+        const uint32_t cnt = popc(R);
+        if (cnt == 0) return 0;
+        all_row_fields<0, PLUS, TR>(R, (t.att | t.def) & C.board, (side ? t.def : t.att) & C.board, C.n, row);
+        return cnt;
+    }
+    // count + dense action mask of one position (mask may be null; it must be zero-initialised by the caller)
+    static TAFL_HD uint32_t movegen(const S& st, const K& C, uint32_t* mask) {
+        return movegen_fields<DIR_VP>(st, C, mask) + movegen_fields<DIR_VM>(st, C, mask) + movegen_fields<DIR_HP>(st, C, mask) + movegen_fields<DIR_HM>(st, C, mask);
     }
     static TAFL_HD int validate(const S& st, tafl_play p, const K& C) { return E::validate(st, p, st.flags & TAFL_F_SIDE, C, nullptr); }
     static TAFL_HD bool side_can_play(const S& st, uint32_t side, const K& C) {
@@ -200,6 +279,10 @@ struct Ops {
     // action index preserves the canonical order).  `mask`: zeroed scratch of mask_words words (LDS on the device).
     static TAFL_HD void step_kth(S& st, uint32_t rank, const K& C, tafl_play* out_play, tafl_effects* eff, uint32_t* mask, uint32_t mask_words) {
         const uint32_t total = movegen(st, C, mask);
+        step_kth_finish(st, rank, total, C, out_play, eff, mask, mask_words);
+    }
+    // second half of step_kth: `mask` holds the dense legal mask of `st`, `total` its number of legal plays
+    static TAFL_HD void step_kth_finish(S& st, uint32_t rank, uint32_t total, const K& C, tafl_play* out_play, tafl_effects* eff, const uint32_t* mask, uint32_t mask_words) {
         tafl_effects e; caps_to_effects(bz<NL>(), 0, e);
         tafl_play pl; pl.from_row = pl.from_col = pl.axis = 0; pl.disp = 0;
         int code;

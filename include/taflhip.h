@@ -206,8 +206,8 @@ typedef struct tafl_mcts_params {
 #define TAFL_MCTS_FLAG_FPU_INF 0x1u
 /* tuning fields of tafl_mcts_params.flags: they choose HOW the same search is executed and never change its results
  * (tests/test_gpu_parity.py::test_mcts_pipelines_agree).
- *   bits 4-7   pipeline: 0 default (two kernels per round: tree phase + playouts over a dense work list), 1 fused (one kernel per
- *              chunk of rounds, at most 2 playout slots per game), 2 two-kernel (explicit)
+ *   bits 4-7   pipeline: 0 default (64-bit boards: fused; wider boards: two kernels per round, tree phase + playouts over dense work
+ *              lists), 1 fused (one kernel per chunk of rounds, at most 2 playout slots per game; 64-bit boards only), 2 two-kernel
  *   bits 8-11  playout slots per game in flight (slot 0 = the pending simulation, the rest are predicted simulations, DESIGN.md
  *              section 6); 0 = chosen from the batch size, at most 8
  *   bits 12-15 partitions of the batch that run the pipeline on their own streams (two-kernel pipeline); 0 = from the batch size, at most 8 */

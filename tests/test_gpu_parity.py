@@ -489,8 +489,9 @@ def test_mcts_pipelines_agree(name, G, sims):
     results = []
     tunes = [abi.mcts_tune(0, 0), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 1), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 2),
              abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 5), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 8),
-             abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 4, 3), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 0, 1),
-             abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 2), abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 1)]
+             abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 4, 3), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 0, 1)]
+    if wb == 64:                      # the fused kernel exists for 64-bit boards only
+        tunes += [abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 2), abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 1)]
     for flags in tunes:
         b = gpu_batch(rules, n, wb, states, G)
         b.mcts_run(sims, 1.0, 3, 300, game_id_base=5, flags=flags)
@@ -504,8 +505,8 @@ def test_mcts_pipelines_agree(name, G, sims):
         b.close()
     for r in results[1:]:
         assert r == results[0]
-    with pytest.raises(Exception):
-        gpu_batch(rules, n, wb, states, G).mcts_run(sims, 1.0, 3, 300, flags=abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 4))
+    with pytest.raises(Exception):                     # fused: at most 2 slots, 64-bit boards only
+        gpu_batch(rules, n, wb, states, G).mcts_run(sims, 1.0, 3, 300, flags=abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 4 if wb == 64 else 2))
     with pytest.raises(Exception):
         gpu_batch(rules, n, wb, states, G).mcts_run(sims, 1.0, 3, 300, flags=1 << 20)
 
@@ -585,7 +586,7 @@ def test_mcts_first_play_urgency_flag_vs_oracle(name, G, sims):
     p = TaflMctsParams(sims, 256, 1.0, 6, 0, abi.MCTS_FLAG_FPU_INF)
     ok, on, _ = orc.batch_mcts(lg, states, K, wb, p, 11)
     results = []
-    for tune in (0, abi.mcts_tune(abi.MCTS_PIPELINE_FUSED, 2), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 8, 1)):
+    for tune in (0, abi.mcts_tune(abi.MCTS_PIPELINE_FUSED if wb == 64 else abi.MCTS_PIPELINE_TWO_KERNEL, 2), abi.mcts_tune(abi.MCTS_PIPELINE_TWO_KERNEL, 8, 1)):
         b = gpu_batch(rules, n, wb, states, G)
         b.mcts_run(sims, 1.0, 6, 256, game_id_base=11, flags=abi.MCTS_FLAG_FPU_INF | tune)
         gk, gn = b.mcts_root_children(256)
