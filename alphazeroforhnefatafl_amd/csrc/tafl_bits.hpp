@@ -66,8 +66,8 @@ TAFL_HD uint32_t mul24(uint32_t a, uint32_t b) {
     return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
 #endif
 }
-template <int W> TAFL_HD uint32_t div_w(uint32_t x) {          // x / W, exact for x < 4694 (W in {7, 11, 15})
-    static_assert(W == 7 || W == 11 || W == 15, "div_w: reciprocal checked for these row widths only");
+template <int W> TAFL_HD uint32_t div_w(uint32_t x) {          // x / W, exact for x < 4694 (W in {7, 11, 13, 15})
+    static_assert(W == 7 || W == 11 || W == 13 || W == 15, "div_w: reciprocal checked for these row widths only");
     return mul24(x, 65536u / (uint32_t)W + 1u) >> 16;
 }
 template <int W> TAFL_HD uint32_t mod_w(uint32_t x) { return x - mul24(div_w<W>(x), (uint32_t)W); }

@@ -158,13 +158,21 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_side_can_play(Consts<NL> C, cons
     constexpr Consts<NL> C##_ct = preset_consts<NL, W, PRESET>();                   \
     const Consts<NL>& C = (PRESET != PRESET_NONE) ? C##_ct : (Carg)
 
-template <int NL, int W, int PRESET>
+// game g of the batch (quad-plane SoA in the reference layout <NLS, WS>) in the layout <NL, W> the kernel works in: the same, or the dense
+// 13-column layout of the 13x13 preset (restride, tafl_core.hpp)
+template <int NLS, int WS, int NL, int W>
+__device__ __forceinline__ void load_batch_state(const Quad* soa, uint32_t n, uint32_t g, uint32_t side_len, DState<NL>& st) {
+    if constexpr (NLS == NL && WS == W) StateIO<NL>::load_soa(soa, n, g, st);
+    else { DState<NLS> t; StateIO<NLS>::load_soa(soa, n, g, t); restride<NLS, WS, NL, W>(t, side_len, st); }
+}
+
+template <int NLS, int WS, int NL, int W, int PRESET>
 __global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK) void k_rollout(Consts<NL> Carg, const Quad* soa, uint32_t n, uint64_t seed, uint32_t sim, uint32_t max_plies,
                                                         uint64_t base, tafl_rollout_result* out) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= n) return;
     TAFL_PICK_CONSTS(C, Carg);
-    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+    DState<NL> st; load_batch_state<NLS, WS, NL, W>(soa, n, g, C.n, st);
     tafl_rollout_result r;
     Ops<NL, W>::rollout(st, seed, base + g, sim, max_plies, C, r);
     out[g] = r;
@@ -192,11 +200,11 @@ __device__ __forceinline__ void stat_add(unsigned long long* stats, int idx, uin
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[idx], (unsigned long long)s);
 }
 
-template <int NL, int W>
+template <int NLS, int WS, int NL, int W>
 __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_init(Consts<NL> C, const Quad* soa, MctsMem M) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= M.G) return;
-    DState<NL> st; StateIO<NL>::load_soa(soa, M.G, g, st);
+    DState<NL> st; load_batch_state<NLS, WS, NL, W>(soa, M.G, g, C.n, st);
     Ops<NL, W>::mcts_init_game(M, g, st, C);
 }
 
@@ -359,7 +367,8 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_best_play(Consts<NL> C, Mct
 // One lane per tile: consecutive lanes write consecutive bytes.
 // self-play step on the device: every game plays the most visited root play of its last search (first maximum, src/mcts.rs:216-227)
 // on its batch state (do_valid_play); games whose root has no visited child (finished games) stay as they are
-template <int NL, int W>
+// NL, W: the batch layout (the play is applied to the batch state); WA: row stride of the search arena the root's plays are recorded in
+template <int NL, int W, int WA>
 __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_play_best(Consts<NL> C, MctsMem M, Quad* soa, tafl_play* out_plays, tafl_effects* eff) {
     const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
     if (g >= M.G) return;
@@ -370,6 +379,7 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_play_best(Consts<NL> C, Mct
         const Edge e = eb[j];
         if (e.n > best) { const NodeHdr ch = M.hdr[(size_t)e.child * M.G + g]; best = e.n; bm.from = ch.mv_from; bm.dir = ch.mv_dir; bm.dist = ch.mv_dist; }
     }
+    if constexpr (WA != W) bm.from = restride_sq<WA, W>(bm.from);
     DState<NL> st; StateIO<NL>::load_soa(soa, M.G, g, st);
     tafl_effects e; Ops<NL, W>::caps_to_effects(bz<NL>(), 0, e);
     tafl_play p; p.from_row = p.from_col = p.axis = 0; p.disp = 0;
@@ -471,6 +481,7 @@ struct tafl_ctx {
     hipStream_t stream;
     bool own_stream;
     Consts<2> c2; Consts<4> c4; Consts<8> c8;
+    Consts<6> c6;                    // the 13x13 preset in the dense 13-column search layout (preset == PRESET_COPENHAGEN13 only)
     int preset;                      // PRESET_* detected at ctx_create: selects kernels with compile-time constants
     hipStream_t part_stream[TAFL_MCTS_MAX_PARTS];   // streams of the partitioned MCTS pipeline ([0] = stream; the others are created on first use)
     hipEvent_t ev_fork[TAFL_MCTS_MAX_PARTS], ev_join[TAFL_MCTS_MAX_PARTS];
@@ -534,6 +545,29 @@ static uint32_t grid_of(uint32_t n) { return (n + TAFL_BLOCK - 1) / TAFL_BLOCK; 
             if ((ctx)->preset == PRESET_COPENHAGEN13) { constexpr int PRESET = PRESET_COPENHAGEN13; STMT; } else { constexpr int PRESET = PRESET_NONE; STMT; } } \
     } while (0)
 
+// the kernels that work on the search arena (and the playouts): NL, W, CC = the arena layout, NLS, WS = the batch layout.  They differ
+// for the 13x13 preset only, which is searched in the dense 13-column layout (6 limbs instead of the reference's 8)
+#define DISPATCH_ARENA(ctx, STMT)                                                                   \
+    do {                                                                                            \
+        if ((ctx)->nl == 2) { constexpr int NL = 2, W = 7, NLS = 2, WS = 7; const Consts<2>& CC = (ctx)->c2; (void)CC; (void)W; (void)NLS; (void)WS; STMT; }        \
+        else if ((ctx)->nl == 4) { constexpr int NL = 4, W = 11, NLS = 4, WS = 11; const Consts<4>& CC = (ctx)->c4; (void)CC; (void)W; (void)NLS; (void)WS; STMT; }  \
+        else if ((ctx)->preset == PRESET_COPENHAGEN13) { constexpr int NL = 6, W = 13, NLS = 8, WS = 15; const Consts<6>& CC = (ctx)->c6; (void)CC; (void)W; (void)NLS; (void)WS; STMT; } \
+        else { constexpr int NL = 8, W = 15, NLS = 8, WS = 15; const Consts<8>& CC = (ctx)->c8; (void)CC; (void)W; (void)NLS; (void)WS; STMT; }                      \
+    } while (0)
+#define DISPATCH_ARENA_PRESET(ctx, STMT)                                                                                  \
+    do {                                                                                                                  \
+        if ((ctx)->nl == 2) { constexpr int NL = 2, W = 7, NLS = 2, WS = 7; const Consts<2>& CC = (ctx)->c2; (void)CC; (void)W; (void)NLS; (void)WS;            \
+            if ((ctx)->preset == PRESET_BRANDUBH7) { constexpr int PRESET = PRESET_BRANDUBH7; STMT; } else { constexpr int PRESET = PRESET_NONE; STMT; } } \
+        else if ((ctx)->nl == 4) { constexpr int NL = 4, W = 11, NLS = 4, WS = 11; const Consts<4>& CC = (ctx)->c4; (void)CC; (void)W; (void)NLS; (void)WS;      \
+            if ((ctx)->preset == PRESET_COPENHAGEN11) { constexpr int PRESET = PRESET_COPENHAGEN11; STMT; } else { constexpr int PRESET = PRESET_NONE; STMT; } } \
+        else if ((ctx)->preset == PRESET_COPENHAGEN13) { constexpr int NL = 6, W = 13, NLS = 8, WS = 15, PRESET = PRESET_COPENHAGEN13; const Consts<6>& CC = (ctx)->c6; (void)CC; (void)W; (void)NLS; (void)WS; STMT; } \
+        else { constexpr int NL = 8, W = 15, NLS = 8, WS = 15, PRESET = PRESET_NONE; const Consts<8>& CC = (ctx)->c8; (void)CC; (void)W; (void)NLS; (void)WS; STMT; } \
+    } while (0)
+template <int NLS> static const Consts<NLS>& batch_consts(const tafl_ctx* c) {
+    if constexpr (NLS == 2) return c->c2; else if constexpr (NLS == 4) return c->c4; else return c->c8;
+}
+static int arena_quads(const tafl_ctx* c) { return c->preset == PRESET_COPENHAGEN13 ? (2 * 6 + 8) / 4 : quads_of(c); }
+
 struct SpanGuard {
     tafl_ctx* c; int idx;
     hipStream_t st;
@@ -592,6 +626,7 @@ int tafl_ctx_create(const tafl_rules* rules, uint8_t side_len, uint32_t word_bit
     if (c->nl == 2) rc = make_consts<2, 7>(*rules, side_len, c->c2);
     else if (c->nl == 4) rc = make_consts<4, 11>(*rules, side_len, c->c4);
     else rc = make_consts<8, 15>(*rules, side_len, c->c8);
+    if (!rc && c->preset == PRESET_COPENHAGEN13) rc = make_consts<6, 13>(*rules, side_len, c->c6);
     if (rc) { delete c; return fail(TAFL_ERR_INVALID_ARG, "bad rules / geometry"); }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(TAFL_ERR_HIP, "hipStreamCreate failed"); } c->own_stream = true; }
@@ -847,7 +882,7 @@ int tafl_rollout(tafl_batch* b, uint64_t seed, uint32_t sim, uint32_t max_plies,
     NEED(b->results, sizeof(tafl_rollout_result) * n);
     {
         SpanGuard sg(c, KC_ROLLOUT);
-        DISPATCH_PRESET(c, hipLaunchKernelGGL((k_rollout<NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, seed, sim, max_plies,
+        DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_rollout<NLS, WS, NL, W, PRESET>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, seed, sim, max_plies,
                                            game_id_base, (tafl_rollout_result*)b->results.p));
     }
     HIPCHK(hipGetLastError());
@@ -876,14 +911,14 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     HIPCHK(hipSetDevice(c->device));
     if (b->has_mem && b->reserved_sims >= max_sims) return TAFL_OK;
     const size_t node_cap = (size_t)max_sims + 1, edge_cap = 4 * ((size_t)max_sims + 1);
-    NEED(b->node_state, node_cap * n * quads_of(c) * sizeof(Quad));
+    NEED(b->node_state, node_cap * n * arena_quads(c) * sizeof(Quad));
     NEED(b->hdr, node_cap * n * sizeof(NodeHdr));
     NEED(b->edges, edge_cap * n * sizeof(Edge));
     NEED(b->node_top, n * 4); NEED(b->edge_top, n * 4); NEED(b->leaf, n * 4);
     NEED(b->kind, n); NEED(b->rvalue, n); NEED(b->fault, n);
     NEED(b->stats, sizeof(unsigned long long) * ST_COUNT);
     const size_t k = b->spec_k;
-    NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * quads_of(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
+    NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * arena_quads(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
     NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_node, k * n * 4); NEED(b->spec_ord, k * n * 4); NEED(b->spec_first, n * 4);
     NEED(b->spec_n, n); NEED(b->spec_w, n); NEED(b->spec_prio, k * n); NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
     NEED(b->ulog_e, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoE)); NEED(b->ulog_h, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoH));
@@ -930,7 +965,7 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     }
     if (fused && slots > 2) return fail(TAFL_ERR_UNSUPPORTED, "the fused pipeline has 1 or 2 playout slots per game");
     if (slots > b->spec_k) slots = b->spec_k;
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_init<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, M));
+    DISPATCH_ARENA(c, hipLaunchKernelGGL((k_mcts_init<NLS, WS, NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, M));
     const uint32_t bps = grid_of(n);
     uint32_t* wlist = (uint32_t*)b->work.p; uint32_t* wcount = (uint32_t*)b->work_count.p;
     if (fused) {
@@ -972,7 +1007,7 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     if (c->rollout_capacity == 0) {
         int blocks = 0; hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, c->device));
-        DISPATCH_PRESET(c, { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_mcts_rollout<NL, W, PRESET>, TAFL_BLOCK, 0) != hipSuccess) blocks = 0; });
+        DISPATCH_ARENA_PRESET(c, { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_mcts_rollout<NL, W, PRESET>, TAFL_BLOCK, 0) != hipSuccess) blocks = 0; });
         if (blocks < 1) blocks = 8;
         c->rollout_capacity = (uint32_t)blocks * (uint32_t)prop.multiProcessorCount * TAFL_BLOCK;
     }
@@ -1037,7 +1072,7 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
             uint32_t* wc_now = pk.wc + (i & 1u) * TAFL_MCTS_MAX_SLOTS; uint32_t* wc_next = pk.wc + ((i + 1u) & 1u) * TAFL_MCTS_MAX_SLOTS;
             {
                 SpanGuard sg(c, KC_MCTS_TREE, pk.s);
-                DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->c_puct, p->n_sims, rounds_left, slots, st,
+                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->c_puct, p->n_sims, rounds_left, slots, st,
                                                       pk.wl, wc_now, pk.g0, pk.g1));
             }
             if (stagger && k + 1 < parts) {       // the next partition's fork event must sit right behind this tree launch
@@ -1046,7 +1081,7 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
             {
                 SpanGuard sg(c, KC_MCTS_ROLLOUT, pk.s);
                 uint32_t* tr = (k == 0 && i < TAFL_MCTS_TRACE_ROUNDS) ? (uint32_t*)b->trace.p + 2 * i : nullptr;      // the first partition's rounds are traced
-                DISPATCH_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(pk.grid_roll), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->seed,
+                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(pk.grid_roll), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->seed,
                                                       game_id_base, p->sim_offset, p->max_rollout_plies, pk.wl, wc_now, wc_next, pk.g1 - pk.g0, pk.cap, st, tr));
             }
         }
@@ -1104,7 +1139,7 @@ int tafl_mcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_ch
     HIPCHK(hipSetDevice(c->device));
     NEED(b->children, sizeof(tafl_root_child) * (size_t)n * max_children); NEED(b->children_n, sizeof(uint32_t) * n);
     HIPCHK(hipMemsetAsync(b->children.p, 0, sizeof(tafl_root_child) * (size_t)n * max_children, c->stream));
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_root_children<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem,
+    DISPATCH_ARENA(c, hipLaunchKernelGGL((k_mcts_root_children<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem,
                                        (tafl_root_child*)b->children.p, max_children, (uint32_t*)b->children_n.p));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, b->children.p, sizeof(tafl_root_child) * (size_t)n * max_children, hipMemcpyDeviceToHost, c->stream));
@@ -1120,7 +1155,7 @@ int tafl_mcts_root_visits(tafl_batch* b, uint32_t* out) {
     HIPCHK(hipSetDevice(c->device));
     NEED(b->visits, sizeof(uint32_t) * (size_t)n * as);
     HIPCHK(hipMemsetAsync(b->visits.p, 0, sizeof(uint32_t) * (size_t)n * as, c->stream));
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_root_visits<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, (uint32_t*)b->visits.p, as));
+    DISPATCH_ARENA(c, hipLaunchKernelGGL((k_mcts_root_visits<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, (uint32_t*)b->visits.p, as));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, b->visits.p, sizeof(uint32_t) * (size_t)n * as, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1155,7 +1190,7 @@ int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visit
     tafl_ctx* c = b->ctx; const uint32_t n = b->n;
     HIPCHK(hipSetDevice(c->device));
     NEED(b->best_plays, sizeof(tafl_play) * n); NEED(b->best_visits, sizeof(uint32_t) * n);
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_best_play<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem,
+    DISPATCH_ARENA(c, hipLaunchKernelGGL((k_mcts_best_play<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem,
                                        (tafl_play*)b->best_plays.p, (uint32_t*)b->best_visits.p));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_plays, b->best_plays.p, sizeof(tafl_play) * n, hipMemcpyDeviceToHost, c->stream));
@@ -1170,7 +1205,7 @@ int tafl_mcts_play_best(tafl_batch* b, tafl_play* out_plays, tafl_effects* out_e
     HIPCHK(hipSetDevice(c->device));
     if (out_plays) NEED(b->best_plays, sizeof(tafl_play) * n);
     if (out_effects) NEED(b->effects, sizeof(tafl_effects) * n);
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_play_best<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, b->soa,
+    DISPATCH_ARENA(c, hipLaunchKernelGGL((k_mcts_play_best<NLS, WS, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, batch_consts<NLS>(c), b->mem, b->soa,
                                        out_plays ? (tafl_play*)b->best_plays.p : nullptr, out_effects ? (tafl_effects*)b->effects.p : nullptr));
     HIPCHK(hipGetLastError());
     if (out_plays) HIPCHK(hipMemcpyAsync(out_plays, b->best_plays.p, sizeof(tafl_play) * n, hipMemcpyDeviceToHost, c->stream));
@@ -1203,7 +1238,7 @@ int tafl_mcts_policy_device_ex(tafl_batch* b, double temp, uint64_t tie_seed, ui
     if (!out_is_device) { NEED(b->policy, bytes); dst = (double*)b->policy.p; }
     HIPCHK(hipMemsetAsync(dst, 0, bytes, c->stream));
     const double inv = temp == 0.0 ? 1.0 : 1.0 / temp;                  // 1. / temp of mcts.py:50
-    DISPATCH_NLW(c, hipLaunchKernelGGL((k_mcts_policy<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, dst, as, temp == 0.0 ? 1 : 0, inv,
+    DISPATCH_ARENA(c, hipLaunchKernelGGL((k_mcts_policy<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->mem, dst, as, temp == 0.0 ? 1 : 0, inv,
                                        tie_seed, game_id_base));
     HIPCHK(hipGetLastError());
     if (!out_is_device) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, c->stream));

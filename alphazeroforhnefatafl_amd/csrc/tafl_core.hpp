@@ -800,6 +800,7 @@ constexpr Consts<NL> preset_consts() {
     if constexpr (PRESET == PRESET_COPENHAGEN11 && NL == 4 && W == 11) return make_consts_ct<NL, W>(rules_copenhagen_ct(), 11);
     else if constexpr (PRESET == PRESET_BRANDUBH7 && NL == 2 && W == 7) return make_consts_ct<NL, W>(rules_brandubh_ct(), 7);
     else if constexpr (PRESET == PRESET_COPENHAGEN13 && NL == 8 && W == 15) return make_consts_ct<NL, W>(rules_copenhagen_ct(), 13);
+    else if constexpr (PRESET == PRESET_COPENHAGEN13 && NL == 6 && W == 13) return make_consts_ct<NL, W>(rules_copenhagen_ct(), 13);   // dense search layout
     else return Consts<NL>{};
 }
 inline bool rules_equal(const tafl_rules& a, const tafl_rules& b) {
@@ -818,6 +819,35 @@ inline int detect_preset(const tafl_rules& r, uint32_t n, uint32_t word_bits) {
     if (n == 13 && word_bits == 256 && rules_equal(r, rules_copenhagen_ct())) return PRESET_COPENHAGEN13;
     return PRESET_NONE;
 }
+
+// ---- the same position with another row stride ----------------------------------------------------------------------------------
+// The reference stores a 13x13 board in a U256 with 15 columns per row (8 limbs of 32 bits).  Searches and playouts of that preset run
+// on a dense 13-column layout (169 bits = 6 limbs): a quarter less work in every multi-limb operation and a register file that holds
+// the playout loop without spilling.  Tile (row, col), the king's (row, col) in `flags` and the repetition ring (it records row / col)
+// do not depend on the stride; only the two board words are re-packed, row by row, when a position enters or leaves that layout.
+template <int NLS, int WS, int NLD, int WD, int R0 = 0>
+TAFL_HD void restride_rows(const Bits<NLS>& a, uint32_t n, Bits<NLD>& d) {
+    constexpr int WMIN = WS < WD ? WS : WD;
+    if constexpr (R0 < WMIN) {
+        if ((uint32_t)R0 < n) {
+            constexpr int ps = R0 * WS, pd = R0 * WD;
+            uint32_t v = a.w[ps >> 5] >> (ps & 31);
+            if constexpr ((ps & 31) + WMIN > 32 && (ps >> 5) + 1 < NLS) v |= a.w[(ps >> 5) + 1] << (32 - (ps & 31));
+            v &= (1u << WMIN) - 1u;
+            d.w[pd >> 5] |= v << (pd & 31);
+            if constexpr ((pd & 31) + WMIN > 32 && (pd >> 5) + 1 < NLD) d.w[(pd >> 5) + 1] |= v >> (32 - (pd & 31));
+        }
+        restride_rows<NLS, WS, NLD, WD, R0 + 1>(a, n, d);
+    }
+}
+template <int NLS, int WS, int NLD, int WD>
+TAFL_HD void restride(const DState<NLS>& s, uint32_t n, DState<NLD>& d) {
+    d.att = bz<NLD>(); d.def = bz<NLD>();
+    restride_rows<NLS, WS, NLD, WD>(s.att, n, d.att); restride_rows<NLS, WS, NLD, WD>(s.def, n, d.def);
+    TAFL_UNROLL for (int i = 0; i < 4; ++i) d.rep[i] = s.rep[i];
+    d.turn = s.turn; d.psc = s.psc; d.reps = s.reps; d.flags = s.flags;
+}
+template <int WS, int WD> TAFL_HD uint32_t restride_sq(uint32_t sq) { const uint32_t r = div_w<WS>(sq); return mul24(r, (uint32_t)WD) + (sq - mul24(r, (uint32_t)WS)); }
 
 // ---- ABI <-> device state conversion (host side) -------------------------------------------------------------------------
 template <int NL>

@@ -19,12 +19,18 @@ static uint32_t g_capacity = 0;        // playouts a round may run (0: all that 
 static std::vector<uint32_t> g_round_work;   // playouts executed per round of the last hs_mcts call (cost-model experiments)
 static bool g_force_generic = false;   // differential tests: generic Engine::rollout vs the fast playout engine
 
-template <int NL, int W>
+// DENSE13: the position arrives in the reference's U256 / 15-column layout and is searched in the dense 13-column layout (6 limbs),
+// as the library does for the 13x13 preset (restride, tafl_core.hpp)
+template <int NL, int W, bool DENSE13 = false>
 struct Host {
     using O = Ops<NL, W>;
     using S = DState<NL>;
     using K = Consts<NL>;
     static int consts(const tafl_rules* r, uint8_t n, K& C) { return make_consts<NL, W>(*r, n, C); }
+    static void load(const tafl_state& a, S& s) {
+        if constexpr (DENSE13) { DState<8> t; state_from_abi<8>(a, t); restride<8, 15, NL, W>(t, 13, s); }
+        else state_from_abi<NL>(a, s);
+    }
 
     static int movegen(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t cnt, uint32_t* counts, uint32_t* masks, uint32_t mw) {
         K C; if (consts(r, n, C)) return -1;
@@ -60,7 +66,7 @@ struct Host {
     }
     static int rollout(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t cnt, uint64_t seed, uint32_t sim, uint32_t max_plies, uint64_t base, tafl_rollout_result* out) {
         K C; if (consts(r, n, C)) return -1;
-        for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::rollout(s, seed, base + g, sim, max_plies, C, out[g], g_force_generic); }
+        for (uint32_t g = 0; g < cnt; ++g) { S s; load(st[g], s); O::rollout(s, seed, base + g, sim, max_plies, C, out[g], g_force_generic); }
         return 0;
     }
     static int random_advance(const tafl_rules* r, uint8_t n, tafl_state* st, uint32_t cnt, uint64_t seed, const uint32_t* plies, uint64_t base) {
@@ -88,7 +94,7 @@ struct Host {
         M.spec_plies = splies.data(); M.spec_node = snode.data(); M.spec_ord = sord.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_w = sw.data(); M.spec_prio = sprio.data();
         M.ulog_e = ue.data(); M.ulog_h = uh.data();
         memset(stats, 0, sizeof *stats);
-        for (uint32_t g = 0; g < G; ++g) { S s; state_from_abi<NL>(st[g], s); O::mcts_init_game(M, g, s, C); }
+        for (uint32_t g = 0; g < G; ++g) { S s; load(st[g], s); O::mcts_init_game(M, g, s, C); }
         g_round_work.clear();
         auto tree = [&](uint32_t rounds_left) {
             for (uint32_t g = 0; g < G; ++g) {
@@ -189,6 +195,11 @@ struct GSession : GSessionBase {
         case 256: return Host<8, 15>::call;                         \
         default:  return -2;                                        \
     }
+// rollouts and searches of 13x13 positions in the dense layout when hs_set_dense13(1) (the other entry points have no dense form)
+static bool g_dense13 = false;
+#define DISPATCH_DENSE(call)                                        \
+    if (g_dense13 && word_bits == 256 && n == 13) return Host<6, 13, true>::call; \
+    DISPATCH(call)
 
 extern "C" {
 void* hs_gmcts_new(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t G, uint32_t max_sims, uint32_t edges_per_node) {
@@ -214,9 +225,10 @@ int hs_validate(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_s
 int hs_step(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const tafl_play* plays, tafl_effects* eff) { DISPATCH(step(r, n, st, cnt, plays, eff)) }
 int hs_step_kth(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff) { DISPATCH(step_kth(r, n, st, cnt, ranks, out_plays, eff)) }
 int hs_side_can_play(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint8_t side, uint8_t* out) { DISPATCH(side_can_play(r, n, st, cnt, side, out)) }
-int hs_rollout(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint64_t seed, uint32_t sim, uint32_t max_plies, uint64_t base, tafl_rollout_result* out) { DISPATCH(rollout(r, n, st, cnt, seed, sim, max_plies, base, out)) }
+int hs_rollout(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint64_t seed, uint32_t sim, uint32_t max_plies, uint64_t base, tafl_rollout_result* out) { DISPATCH_DENSE(rollout(r, n, st, cnt, seed, sim, max_plies, base, out)) }
 int hs_random_advance(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, uint64_t seed, const uint32_t* plies, uint64_t base) { DISPATCH(random_advance(r, n, st, cnt, seed, plies, base)) }
-int hs_mcts(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_mcts_params* p, uint64_t base, tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) { DISPATCH(mcts(r, n, st, cnt, p, base, out_children, max_children, out_n, stats)) }
+int hs_mcts(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_mcts_params* p, uint64_t base, tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) { DISPATCH_DENSE(mcts(r, n, st, cnt, p, base, out_children, max_children, out_n, stats)) }
+void hs_set_dense13(int on) { g_dense13 = on != 0; }
 }
 
 #ifdef TAFL_STAT

@@ -47,6 +47,8 @@ def lib():
         L.hs_gmcts_counts.argtypes = [vp, P(u64)]
         L.hs_set_spec_target.restype = None
         L.hs_set_spec_target.argtypes = [C.c_uint32]
+        L.hs_set_dense13.restype = None
+        L.hs_set_dense13.argtypes = [C.c_int]
         L.hs_set_capacity.restype = None
         L.hs_set_capacity.argtypes = [C.c_uint32]
         L.hs_round_work.restype = C.c_uint32
@@ -131,3 +133,8 @@ def round_work():
     buf = (C.c_uint32 * 4096)()
     n = lib().hs_round_work(buf, 4096)
     return list(buf[:min(n, 4096)])
+
+
+def set_dense13(on: bool):
+    """Rollouts / searches of 13x13 positions in the dense 13-column layout (what the library does for the 13x13 preset)."""
+    lib().hs_set_dense13(int(on))

@@ -544,11 +544,12 @@ def test_batched_game_history_and_undo():
             assert len(bg.play_history[g]) == len(og[g].play_history)
 
 
-def test_mcts_play_best_is_best_play_plus_do_play():
+@pytest.mark.parametrize("name,G", [("brandubh7", 96), ("copenhagen13", 48)])
+def test_mcts_play_best_is_best_play_plus_do_play(name, G):
     """tafl_mcts_play_best (device-side self-play step) == tafl_mcts_best_play + tafl_step, and a short self-play loop stays
-    in step with the oracle driven by the same plays."""
-    rules, fen, wb, n, lg = _mk("brandubh7")
-    G = 96
+    in step with the oracle driven by the same plays.  (13x13: the search runs in the dense 13-column layout, the play is applied to
+    the batch state in the reference's 15-column layout.)"""
+    rules, fen, wb, n, lg = _mk(name)
     states = pu.start_states(orc, fen, rules.starting_side, wb, G)
     a = gpu_batch(rules, n, wb, states, G)
     ostates = pu.clone_states(states, G)

@@ -101,3 +101,35 @@ def test_fast_shieldwall_hint_many_seeds(n, wb):
     for v in variants:
         for seed in range(12):
             _compare(v, n, wb, states, len(lst), 100 + seed, 3, ("swhint", n, seed))
+
+
+def test_dense_13_column_layout_matches_the_oracle():
+    """13x13 positions searched in the dense 13-column layout (6 limbs) that the library uses for the 13x13 preset: rollouts and MCTS
+    root statistics equal the oracle's (which works on the reference's U256 / 15-column words), from the start and from mid-game."""
+    from alphazeroforhnefatafl_amd.abi import TaflMctsParams
+    from tests.hostsim import hostsim
+    rules, fen, wb = pu.CONFIGS["copenhagen13"]
+    n, G = 13, 24
+    lg, hs = orc.GameLogic(rules, n), HostSim(rules, n, wb)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 11) % 90 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 5, plies, 3)
+    want = orc.batch_rollout(lg, states, G, wb, 9, 2, 400, 3)
+    p = TaflMctsParams(40, 300, 1.0, 4, 0, 0)
+    ok, on, ostats = orc.batch_mcts(lg, states, G, wb, p, 3)
+    hostsim.set_dense13(True)
+    try:
+        got = hs.rollout(states, G, 9, 2, 400, 3)
+        hk, hn, hstats = hs.mcts(states, G, p, 3)
+    finally:
+        hostsim.set_dense13(False)
+    for g in range(G):
+        assert (want[g].value, want[g].status, want[g].reason, want[g].winner, want[g].plies) == \
+               (got[g].value, got[g].status, got[g].reason, got[g].winner, got[g].plies), g
+    assert list(on) == list(hn)
+    for g in range(G):
+        for j in range(on[g]):
+            a, b = ok[g * 256 + j], hk[g * 256 + j]
+            assert (pu.play_tuple4(a.play), a.action, a.visits, float(a.q).hex()) == (pu.play_tuple4(b.play), b.action, b.visits, float(b.q).hex()), (g, j)
+    for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+        assert getattr(ostats, f) == getattr(hstats, f), f
