@@ -383,6 +383,27 @@ struct Ops {
         const double sq = sqrt((double)h.ns);
         double cur_best = -__builtin_inf(); int best = -1;
         const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+        if (h.m < h.n_legal && c_puct >= 0.0) {
+            // While an unvisited action exists it scores u0 = cp * sqrt(Ns + EPS) > cp * sqrt(Ns) / 2 >= cp * sqrt(Ns) / (1 + Nsa) for every
+            // visited one (Nsa >= 1), so a visited action with Qsa <= 0 can neither win nor tie: only the (few) actions with Qsa > 0 are
+            // evaluated, in ascending order as mcts.py does - the float64 division is the expensive part of this loop and 64 games share
+            // an instruction stream (-24 % VALU instructions in k_mcts_tree).  Same argmax, same tie rule.
+            const double u0 = cp * sqrt((double)h.ns + TAFL_MCTS_EPS);
+            for (uint32_t j0 = 0; j0 < h.m; j0 += 32) {
+                uint32_t pos = 0;
+                const uint32_t lim = h.m - j0 < 32u ? h.m - j0 : 32u;
+                for (uint32_t t = 0; t < lim; ++t) pos |= (eb[j0 + t].q > 0.0 ? 1u : 0u) << t;
+                while (pos) {
+                    const uint32_t t = (uint32_t)__builtin_ctz(pos);
+                    pos &= pos - 1u;
+                    const Edge e = eb[j0 + t];
+                    const double u = e.q + cp * sq / (double)(1 + e.n);
+                    if (u > cur_best) { cur_best = u; best = (int)(j0 + t); }
+                }
+            }
+            if (u0 > cur_best) { cur_best = u0; best = (int)h.m; }
+            return best;
+        }
         // the edge records are fetched eight at a time (independent loads in flight: this loop is bound by memory latency),
         // then evaluated in ascending order as mcts.py does
         for (uint32_t j0 = 0; j0 < h.m; j0 += 8) {
@@ -584,7 +605,9 @@ struct Ops {
     // rounds_left: rounds the host still plans for this search (0: issue spec_k slots whenever possible): a game issues
     // ceil(remaining / rounds_left) slots, so that a game that lost a round to a misprediction catches up instead of trailing.
     // target: slots per game and round the plan is made for (0: none).  spec_prio: priority class of a slot in the round's work lists.
-    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, const K& C, LaneStats& ls) {
+    // wcap: most predicted simulations a game may run beside the pending one (the host lowers it while few predictions come true: a
+    // prediction costs a child expansion in the tree phase whether it is consumed or not).
+    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, uint32_t wcap, const K& C, LaneStats& ls) {
         uint32_t sim = M.sim_next[g];
         if (M.kind[g] == 1) {                                    // slot 0 of the previous call
             if (M.spec_kind[g] != 2) return;                     // its playout has not run yet (the round was full): the slots stay requested
@@ -634,8 +657,9 @@ struct Ops {
             }
             if (w > M.spec_k - 1) w = M.spec_k - 1;
             M.spec_w[g] = (uint8_t)w;
-            // rounds_left == 1: the plan is through and only trailing games are left; the device is nearly empty, so a wasted playout
-            // costs nothing and every slot that exists is used
+            if (w > wcap) w = wcap;
+            // rounds_left == 1: the plan is through and the device is emptying (the host says so): a wasted playout costs nothing, every slot
+            // that exists is used.  rounds_left == 0: no plan, the game keeps to its own hit history.
             uint32_t want = M.spec_k;
             if (rounds_left > 1) {
                 const uint32_t rem = n_sims - sim;

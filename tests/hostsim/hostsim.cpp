@@ -99,7 +99,7 @@ struct Host {
         auto tree = [&](uint32_t rounds_left) {
             for (uint32_t g = 0; g < G; ++g) {
                 LaneStats ls; memset(&ls, 0, sizeof ls);
-                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, rounds_left, g_spec_target, C, ls);
+                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, rounds_left, g_spec_target, g_spec_k, C, ls);
                 stats->sims += ls.sims; stats->tree_depth_sum += ls.depth; stats->children_scanned += ls.scanned;
                 stats->terminal_hits += ls.terminal_hits; stats->faults += ls.faults;
                 stats->rollouts += ls.rollouts; stats->rollout_plies += ls.rollout_plies;
