@@ -53,8 +53,8 @@ def main():
             out[k]["valu_issue_fraction_of_peak"] = s["SQ_INSTS_VALU"] / (cyc * 1024 / 4.0)
     json.dump(out, open(os.path.join(a.out, "pmc_summary.json"), "w"), indent=1)
     if a.traffic_json:
-        k = next((k for k in out if "k_mcts_fused" in k), None) or next(k for k in out if "k_mcts_rollout" in k)
-        json.dump({"kernel": k, "config": "bench.py defaults (65536 games, S=64, 2 playout slots per game)", "note": "algorithmic_bytes_per_step is taken from the same run's bench line (roofline.algorithmic_bytes)",
+        k = next(k for k in out if "k_mcts_rollout" in k)
+        json.dump({"kernel": k, "config": "bench.py defaults (65536 games, 11x11 Copenhagen, S=64, two-kernel pipeline)", "note": "algorithmic_bytes_per_step is taken from the same run's bench line (roofline.algorithmic_bytes)",
                    "source": os.path.join(a.out, "pmc_summary.json") + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, one bench step)",
                    "fetch_size_kb_per_step_raw": out[k]["FETCH_SIZE_KB_per_step_raw"], "write_size_kb_per_step": out[k]["WRITE_SIZE_KB_per_step"],
                    "correction": "gfx950 FETCH_SIZE reports 1/2 of wide (16 B/lane) coalesced reads: doubled (MI355X_MICROARCH.md, HBM)",
