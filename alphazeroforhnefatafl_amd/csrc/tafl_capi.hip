@@ -39,13 +39,13 @@ extern "C" int tafl_prof_read(unsigned long long* out, int reset) {
 #ifndef TAFL_KATTR
 #define TAFL_KATTR
 #endif
-// the MCTS pipeline runs spec_k (default 2) playout waves per SIMD.  Measured on MI355X: a SIMD issues one of these integer
-// wave-instructions per 4 cycles and a single playout wave already reaches ~65 % of that; the second wave fills most of the
-// rest (+18 %), more waves add nothing.
+// minimum waves per SIMD the playout kernels are compiled for (a bound for the register allocator; the preset 11x11 kernel needs 104
+// VGPRs and runs four, which is what the pipeline fills: DESIGN.md section 6)
 #ifndef TAFL_ROLLOUT_WAVES
 #define TAFL_ROLLOUT_WAVES 2
 #endif
 #define TAFL_MCTS_MAX_SLOTS 8        /* playout slots per game (slot 0 + up to 7 predicted simulations) */
+static_assert(TAFL_MCTS_MAX_SLOTS == tafl::kMctsMaxSlots, "slot bound of tafl_ops.hpp");
 #define TAFL_MCTS_MAX_PARTS 8         /* partitions of a batch that run the two-kernel pipeline on their own streams */
 #define TAFL_MCTS_TRACE_ROUNDS 4096   /* rounds of a search whose work counts are kept for tafl_mcts_round_trace */
 #define TAFL_MCTS_UNDO_CAP 64        /* undo records per game and speculation pass (edges and headers each) */
@@ -229,25 +229,25 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
         const unsigned long long fin = __ballot(live && M.sim_next[g] >= n_sims && M.kind[g] != 1);
         if ((threadIdx.x & 63u) == 0 && fin) atomicAdd(&stats[ST_DONE], (unsigned long long)__popcll(fin));
     }
-    // dense work lists of the playouts this round has to run, one list per priority class (work[p * stride ..], work_count[p]; entry =
-    // slot << 27 | game): the playout kernel walks them in class order up to what the device holds at once, so that the most speculative
-    // playouts are the ones left for the next round when more is asked for (one atomic per wave, slot and class)
+    // dense work lists of the playouts this round has to run, one list per priority class = slot index (work[j * stride ..], work_count[j];
+    // entry = slot << 27 | game): the playout kernel walks them in class order up to what the device holds at once, so that the most
+    // speculative playouts are the ones left for the next round when more is asked for.  One atomic per wave and slot; the loads of all
+    // slots, then the atomics of all slots are in flight together (a dependent chain of eight was 8 round trips to L2).
     const uint32_t stride = g_end - g_begin;
-    for (uint32_t j = 0; j < M.spec_k; ++j) {
-        const bool need = live && j < M.spec_n[g] && M.spec_kind[(size_t)j * M.G + g] == 1;
-        const uint32_t pr = need ? M.spec_prio[(size_t)j * M.G + g] : 0u;
-        unsigned long long rest = __ballot(need);
-        while (rest != 0ull) {                                   // one pass per class present in the wave (normally one)
-            const int first = __ffsll((long long)rest) - 1;
-            const uint32_t cls = (uint32_t)__shfl((int)pr, first);
-            const unsigned long long bal = __ballot(need && pr == cls) & rest;
-            const uint32_t lane = threadIdx.x & 63u;
-            uint32_t base = 0;
-            if ((int)lane == first) base = atomicAdd(&work_count[cls], (uint32_t)__popcll(bal));
-            base = (uint32_t)__shfl((int)base, first);
-            if ((bal >> lane) & 1ull) work[(size_t)cls * stride + base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (j << 27) | g;
-            rest &= ~bal;
-        }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sn = live ? (uint32_t)M.spec_n[g] : 0u;
+    uint8_t kd[TAFL_MCTS_MAX_SLOTS];
+    TAFL_UNROLL for (uint32_t j = 0; j < TAFL_MCTS_MAX_SLOTS; ++j) kd[j] = (live && j < M.spec_k) ? M.spec_kind[(size_t)j * M.G + g] : (uint8_t)0;
+    unsigned long long bal[TAFL_MCTS_MAX_SLOTS]; uint32_t base[TAFL_MCTS_MAX_SLOTS];
+    TAFL_UNROLL for (uint32_t j = 0; j < TAFL_MCTS_MAX_SLOTS; ++j) {
+        bal[j] = __ballot(j < sn && kd[j] == 1);
+        base[j] = 0;
+        if (bal[j] != 0ull && (int)lane == __ffsll((long long)bal[j]) - 1) base[j] = atomicAdd(&work_count[j], (uint32_t)__popcll(bal[j]));
+    }
+    TAFL_UNROLL for (uint32_t j = 0; j < TAFL_MCTS_MAX_SLOTS; ++j) {
+        if (bal[j] == 0ull) continue;
+        const uint32_t b0 = (uint32_t)__shfl((int)base[j], __ffsll((long long)bal[j]) - 1);
+        if ((bal[j] >> lane) & 1ull) work[(size_t)j * stride + b0 + (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1ull))] = (j << 27) | g;
     }
     stat_add(stats, ST_SIMS, ls.sims); stat_add(stats, ST_DEPTH, ls.depth); stat_add(stats, ST_SCANNED, ls.scanned);
     stat_add(stats, ST_TERMINAL, ls.terminal_hits); stat_add(stats, ST_FAULTS, ls.faults);
@@ -518,7 +518,7 @@ struct tafl_batch {
     DevBuf best_plays, best_visits, enc, policy;
     DevBuf work, work_count, trace;
     uint32_t trace_rounds;           // rounds of the last two-kernel search recorded in `trace` (requested / run playouts per round)
-    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_node, spec_ord, spec_first, spec_n, spec_w, spec_prio, ulog_e, ulog_h;
+    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_node, spec_ord, spec_first, spec_n, spec_w, ulog_e, ulog_h;
     uint32_t spec_k;                 // playout slots per game that exist (TAFL_MCTS_MAX_SLOTS)
     tafl_mcts_stats last_stats; bool ran;
     // guided MCTS (external evaluator)
@@ -719,7 +719,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_meta, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->spec_prio, &b->ulog_e, &b->ulog_h, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace,
+                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->ulog_e, &b->ulog_h, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
                       &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
     for (DevBuf* d : bufs) d->release();
@@ -922,7 +922,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     const size_t k = b->spec_k;
     NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * arena_quads(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
     NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_node, k * n * 4); NEED(b->spec_ord, k * n * 4); NEED(b->spec_first, n * 4);
-    NEED(b->spec_n, n); NEED(b->spec_w, n); NEED(b->spec_prio, k * n); NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
+    NEED(b->spec_n, n); NEED(b->spec_w, n); NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
     NEED(b->ulog_e, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoE)); NEED(b->ulog_h, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoH));
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
@@ -930,7 +930,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p; b->mem.spec_meta = (uint32_t*)b->spec_meta.p;
     b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
     b->mem.spec_node = (uint32_t*)b->spec_node.p; b->mem.spec_ord = (uint32_t*)b->spec_ord.p; b->mem.spec_first = (uint32_t*)b->spec_first.p;
-    b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_w = (uint8_t*)b->spec_w.p; b->mem.spec_prio = (uint8_t*)b->spec_prio.p; b->mem.spec_k = b->spec_k;
+    b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_w = (uint8_t*)b->spec_w.p; b->mem.spec_k = b->spec_k;
     b->mem.ulog_e = (UndoE*)b->ulog_e.p; b->mem.ulog_h = (UndoH*)b->ulog_h.p; b->mem.ulog_cap = TAFL_MCTS_UNDO_CAP;
     b->mem.G = b->n; b->mem.node_cap = (uint32_t)node_cap; b->mem.edge_cap = (uint32_t)edge_cap;
     b->mem.flags = 0;

@@ -1,5 +1,5 @@
 // tafl_ops.hpp — per-game operations behind the C-ABI entry points, written once as
-// __host__ __device__ functions: the HIP kernels (tafl_kernels.hip) run them one game per lane,
+// __host__ __device__ functions: the HIP kernels (tafl_capi.hip) run them one game per lane,
 // tests/hostsim runs the identical code in a CPU loop for differential testing against the oracle.
 //
 // MCTS: the arithmetic of src/mcts.py:55-136 (select :104-123, expand :83-102, backup :127-136)
@@ -98,7 +98,6 @@ struct MctsMem {
     uint32_t* spec_ord;          // [j * G + g] ... of this node (the child's index in the node's edge list when it is really expanded)
     uint32_t* spec_first;        // [G] simulation index of slot 0
     uint8_t* spec_n;             // [G] slots issued (placeholders of predicted terminal revisits included)
-    uint8_t* spec_prio;          // [j * G + g] priority class of slot j in the round's work lists (0 first)
     uint8_t* spec_w;             // [G] speculative slots this game may issue next (grows by one per fully consumed issue, shrinks to
                                  //     what was consumed + 1 after a misprediction)
     UndoE* ulog_e;               // [g * ulog_cap + i]
@@ -115,6 +114,7 @@ struct LaneStats {
     uint32_t spec_issued, spec_hits;
 };
 
+constexpr uint32_t kMctsMaxSlots = 8;     // playout slots per game that can exist (MctsMem::spec_k <= this): bound of the unrolled slot loops
 #define TAFL_MCTS_EPS 1e-8       /* src/mcts.py:6 */
 #define TAFL_DRAW_VALUE 1e-4     /* getGameEnded draw convention, DESIGN.md */
 
@@ -392,7 +392,13 @@ struct Ops {
             for (uint32_t j0 = 0; j0 < h.m; j0 += 32) {
                 uint32_t pos = 0;
                 const uint32_t lim = h.m - j0 < 32u ? h.m - j0 : 32u;
-                for (uint32_t t = 0; t < lim; ++t) pos |= (eb[j0 + t].q > 0.0 ? 1u : 0u) << t;
+                // eight independent loads in flight per step (one load and one wait per edge made this scan the longest dependent
+                // chain of the tree phase: every wait is a trip to L2 / HBM)
+                for (uint32_t t0 = 0; t0 < lim; t0 += 8) {
+                    double q[8];
+                    TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) q[t] = eb[j0 + (t0 + t < lim ? t0 + t : lim - 1u)].q;
+                    TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) pos |= ((t0 + t < lim && q[t] > 0.0) ? 1u : 0u) << (t0 + t);
+                }
                 while (pos) {
                     const uint32_t t = (uint32_t)__builtin_ctz(pos);
                     pos &= pos - 1u;
@@ -419,6 +425,16 @@ struct Ops {
             if (u0 > cur_best) { cur_best = u0; best = (int)h.m; }
         }
         return best;
+    }
+
+    // edge array of a node moved to a larger allocation: four records in flight (a load, a wait and a store per record is one memory
+    // round trip per record, and the whole wave waits for the game with the longest array)
+    static TAFL_HD void copy_edges(Edge* dst, const Edge* src, uint32_t n) {
+        for (uint32_t j = 0; j < n; j += 4) {
+            Edge t4[4];
+            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) t4[t] = src[j + t < n ? j + t : n - 1u];
+            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) if (j + t < n) dst[j + t] = t4[t];
+        }
     }
 
     // select + expand of simulation number `sim` (mcts.py:77-123).  Leaves M.leaf/M.kind set for the rollout + backup.
@@ -459,8 +475,7 @@ struct Ops {
                 const uint32_t ncap = cap ? cap * 2u : 4u;
                 const uint32_t nbase = M.edge_top[g];
                 if (id >= M.node_cap || nbase + ncap > M.edge_cap) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
-                Edge* dst = &M.edges[(size_t)g * M.edge_cap + nbase];
-                for (uint32_t j = 0; j < h.m; ++j) dst[j] = eb[j];
+                copy_edges(&M.edges[(size_t)g * M.edge_cap + nbase], eb, h.m);
                 M.edge_top[g] = nbase + ncap; base = nbase; cap = ncap;
             } else if (id >= M.node_cap) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
             Edge ne; ne.q = 0.0; ne.n = 0; ne.child = id;
@@ -571,9 +586,7 @@ struct Ops {
                 if (h.m == cap) {                                 // uncommitted growth into free arena space
                     const uint32_t ncap = cap ? cap * 2u : 4u;
                     if (vtop + ncap > M.edge_cap) { stop = true; break; }
-                    Edge* dst = &M.edges[(size_t)g * M.edge_cap + vtop];
-                    const Edge* src = &M.edges[(size_t)g * M.edge_cap + base];
-                    for (uint32_t j = 0; j < h.m; ++j) dst[j] = src[j];
+                    copy_edges(&M.edges[(size_t)g * M.edge_cap + vtop], &M.edges[(size_t)g * M.edge_cap + base], h.m);
                     base = vtop; cap = ncap; vtop += ncap;
                 }
                 Edge ne; ne.q = 0.0; ne.n = 0; ne.child = VIRT_CHILD;
@@ -596,15 +609,25 @@ struct Ops {
             cnt = t + 1;
         }
         // restore the tree (reverse order: a record may have been logged more than once)
-        for (uint32_t i = L.ne; i > 0; --i) { const UndoE u = L.e[i - 1]; M.edges[(size_t)g * M.edge_cap + u.idx] = u.e; }
-        for (uint32_t i = L.nh; i > 0; --i) { const UndoH u = L.h[i - 1]; M.hdr[(size_t)u.node * M.G + g] = u.h; }
+        // (the records are fetched four at a time, the stores keep their order)
+        for (uint32_t i = L.ne; i > 0; i -= (i < 4u ? i : 4u)) {
+            UndoE u[4];
+            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) u[t] = L.e[t < i ? i - 1u - t : 0u];
+            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) if (t < i) M.edges[(size_t)g * M.edge_cap + u[t].idx] = u[t].e;
+        }
+        for (uint32_t i = L.nh; i > 0; i -= (i < 4u ? i : 4u)) {
+            UndoH u[4];
+            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) u[t] = L.h[t < i ? i - 1u - t : 0u];
+            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) if (t < i) M.hdr[(size_t)u[t].node * M.G + g] = u[t].h;
+        }
         return cnt;
     }
 
     // One call advances game g by as many simulations as it can without waiting for a playout.
     // rounds_left: rounds the host still plans for this search (0: issue spec_k slots whenever possible): a game issues
     // ceil(remaining / rounds_left) slots, so that a game that lost a round to a misprediction catches up instead of trailing.
-    // target: slots per game and round the plan is made for (0: none).  spec_prio: priority class of a slot in the round's work lists.
+    // target: slots per game and round the plan is made for (0: none).  The slot index is the slot's priority class in the round's work
+    // lists: slot 0 (certain) first, the most speculative last.
     // wcap: most predicted simulations a game may run beside the pending one (the host lowers it while few predictions come true: a
     // prediction costs a child expansion in the tree phase whether it is consumed or not).
     static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, uint32_t wcap, const K& C, LaneStats& ls) {
@@ -643,7 +666,9 @@ struct Ops {
             uint32_t w = M.spec_w[g];
             if (had > 1) {
                 uint32_t issued = 0;
-                for (uint32_t t = 1; t < had; ++t) { const uint8_t sk = M.spec_kind[(size_t)t * M.G + g]; issued += (sk == 1 || sk == 2) ? 1u : 0u; }
+                uint8_t sk[kMctsMaxSlots];
+                TAFL_UNROLL for (uint32_t t = 1; t < kMctsMaxSlots; ++t) sk[t] = M.spec_kind[(size_t)(t < had ? t : 0u) * M.G + g];      // independent loads
+                TAFL_UNROLL for (uint32_t t = 1; t < kMctsMaxSlots; ++t) issued += (t < had && (sk[t] == 1 || sk[t] == 2)) ? 1u : 0u;
 #ifndef TAFL_SPEC_POLICY
 #define TAFL_SPEC_POLICY 1
 #endif
@@ -669,7 +694,6 @@ struct Ops {
             if (want > M.spec_k) want = M.spec_k;
             uint32_t cnt = 1;
             if (want > 1 && sim + 1 < n_sims && M.ulog_cap > 0) cnt = mcts_speculate(M, g, L, sim, want, c_puct, n_sims, 0.0, C, ls);
-            for (uint32_t t = 0; t < cnt; ++t) M.spec_prio[(size_t)t * M.G + g] = (uint8_t)t;      // slot 0 (certain) first, the most speculative last
             for (uint32_t t = cnt; t < M.spec_k; ++t) M.spec_kind[(size_t)t * M.G + g] = 0;
             M.spec_n[g] = (uint8_t)cnt; M.spec_first[g] = sim;
             break;                                                                  // wait for the playouts

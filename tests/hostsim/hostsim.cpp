@@ -85,13 +85,13 @@ struct Host {
         std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
         std::vector<Edge> edges((size_t)M.edge_cap * G);
         std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sfirst(G), splies((size_t)M.spec_k * G), smeta((size_t)M.spec_k * G), snode((size_t)M.spec_k * G), sord((size_t)M.spec_k * G);
-        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), sw(G), sprio((size_t)M.spec_k * G);
+        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), sw(G);
         std::vector<int8_t> rv(G), sval((size_t)M.spec_k * G);
         std::vector<UndoE> ue((size_t)(M.ulog_cap ? M.ulog_cap : 1) * G); std::vector<UndoH> uh((size_t)(M.ulog_cap ? M.ulog_cap : 1) * G);
         M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
         M.leaf = leaf.data(); M.kind = kind.data(); M.rvalue = rv.data(); M.fault = fault.data();
         M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data(); M.spec_meta = smeta.data();
-        M.spec_plies = splies.data(); M.spec_node = snode.data(); M.spec_ord = sord.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_w = sw.data(); M.spec_prio = sprio.data();
+        M.spec_plies = splies.data(); M.spec_node = snode.data(); M.spec_ord = sord.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_w = sw.data();
         M.ulog_e = ue.data(); M.ulog_h = uh.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; load(st[g], s); O::mcts_init_game(M, g, s, C); }
@@ -112,13 +112,12 @@ struct Host {
             tree(g_spec_target ? (i < planned ? planned - i : 1u) : 0u);
             // slot-major like the device's per-slot work lists; with a capacity, playouts beyond it wait for the next round
             uint32_t work = 0;
-            for (uint32_t pr = 0; pr < M.spec_k; ++pr)
-                for (uint32_t j = 0; j < M.spec_k; ++j)
-                    for (uint32_t g = 0; g < G; ++g) {
-                        if (!(j < sn[g] && skind[(size_t)j * G + g] == 1 && sprio[(size_t)j * G + g] == pr)) continue;
-                        if (g_capacity && work >= g_capacity) continue;
-                        ++work; O::mcts_slot_rollout(M, j, g, p->seed, base + g, p->sim_offset, p->max_rollout_plies, C);
-                    }
+            for (uint32_t j = 0; j < M.spec_k; ++j)
+                for (uint32_t g = 0; g < G; ++g) {
+                    if (!(j < sn[g] && skind[(size_t)j * G + g] == 1)) continue;
+                    if (g_capacity && work >= g_capacity) continue;
+                    ++work; O::mcts_slot_rollout(M, j, g, p->seed, base + g, p->sim_offset, p->max_rollout_plies, C);
+                }
             if (work == 0) break;
             g_round_work.push_back(work);
         }

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "tafl_host.hpp"
@@ -18,6 +19,12 @@ using namespace tafl;
 
 #ifndef LB
 #define LB 1
+#endif
+#ifdef TAFL_PROF
+// -DTAFL_PROF: per-section shader-clock totals of the playout loop (tafl_bits.hpp TAFL_PROF_*): where the cycles of one ply go
+extern "C" __device__ unsigned long long tafl_prof_acc[4096 * 32] = {};
+static const char* const PROF_NAME[12] = {"pick", "captures: custodial fields", "captures: king", "captures: shieldwall filter", "removal + repetition tracker", "T-layout upkeep",
+                                          "gen (next mover's four reach sets)", "outcome + finish", "  of which enclosure flood", "  of which exit fort", "empty mark", "empty mark"};
 #endif
 
 template <int NL, int W, int PRESET>
@@ -44,7 +51,7 @@ int run(const char* board, uint32_t word_bits, uint32_t max_plies, int reps) {
     tafl_state st; std::string err;
     if (fen_to_state(preset_board(board), 0, word_bits, &st, &err)) { fprintf(stderr, "fen: %s\n", err.c_str()); return 1; }
     DState<NL> ds; state_from_abi<NL>(st, ds);
-    for (int waves = 1; waves <= 4; ++waves) {
+    for (int waves = 1; waves <= (LB > 4 ? LB : 4); ++waves) {
         const uint32_t n = 65536u * (uint32_t)waves;
         Quad* soa; tafl_rollout_result* out;
         CK(hipMalloc(&soa, sizeof(Quad) * StateIO<NL>::QUADS * n)); CK(hipMalloc(&out, sizeof(tafl_rollout_result) * n));
@@ -64,6 +71,21 @@ int run(const char* board, uint32_t word_bits, uint32_t max_plies, int reps) {
         for (uint32_t g = 0; g < n; ++g) { plies += h[g].plies; sum = sum * 1000003ull + (unsigned long long)(h[g].plies * 16u + h[g].reason) + (unsigned long long)(h[g].value + 2); capped += h[g].reason == 14; }
         // checksum over the first 65 536 games only would be waves-independent; print both
         unsigned long long sum0 = 0; for (uint32_t g = 0; g < 65536u; ++g) sum0 = sum0 * 1000003ull + (unsigned long long)(h[g].plies * 16u + h[g].reason) + (unsigned long long)(h[g].value + 2);
+#ifdef TAFL_PROF
+        {
+            static unsigned long long hp[4096 * 32];
+            CK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(tafl_prof_acc), sizeof hp));
+            unsigned long long tot[32] = {0};
+            for (int w = 0; w < 4096; ++w) for (int k = 0; k < 32; ++k) tot[k] += hp[w * 32 + k];
+            const double iters = (double)tot[31];                  // wave-iterations of the loop over all timed launches
+            const double mark = (double)(long long)tot[10] / iters;   // cost of one mark pair
+            printf("# waves_per_simd %d: shader-clock ticks per wave-iteration (100 MHz clock; one mark costs %.2f ticks, subtracted)\n", waves, mark);
+            double sum = 0;
+            for (int k = 0; k < 10; ++k) { const double v = (double)(long long)tot[k] / iters - ((k < 8) ? mark : 0.0); if (k < 8) sum += v; printf("#   %-38s %8.2f\n", PROF_NAME[k], v); }
+            printf("#   %-38s %8.2f\n", "sum of sections 0-7", sum);
+            memset(hp, 0, sizeof hp); CK(hipMemcpyToSymbol(HIP_SYMBOL(tafl_prof_acc), hp, sizeof hp));
+        }
+#endif
         printf("{\"board\": \"%s\", \"lb\": %d, \"waves_per_simd\": %d, \"games\": %u, \"ms\": %.4f, \"plies\": %llu, \"Gplies_per_s\": %.3f, "
                "\"ns_per_wave_ply_per_simd\": %.3f, \"capped_frac\": %.3f, \"checksum64k\": \"%016llx\"}\n",
                board, LB, waves, n, best, plies, plies / (best * 1e6), best * 1e6 / ((double)max_plies * waves), (double)capped / n, sum0);
