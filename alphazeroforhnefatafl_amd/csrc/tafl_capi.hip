@@ -514,7 +514,7 @@ struct tafl_batch {
     DevBuf plays, effects, counts, masks, codes, ranks, results, out_plays, u8out, plies;
     // MCTS
     MctsMem mem; bool has_mem; uint32_t reserved_sims;
-    DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, rvalue, fault, stats, children, children_n, visits;
+    DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, fault, stats, children, children_n, visits;
     DevBuf best_plays, best_visits, enc, policy;
     DevBuf work, work_count, trace;
     uint32_t trace_rounds;           // rounds of the last two-kernel search recorded in `trace` (requested / run playouts per round)
@@ -717,7 +717,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     (void)hipStreamSynchronize(b->ctx->stream);
     if (b->soa) (void)hipFree(b->soa);
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
-                      &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->rvalue, &b->fault, &b->stats,
+                      &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_meta, &b->spec_value, &b->spec_kind, &b->spec_reason,
                       &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->ulog_e, &b->ulog_h, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
@@ -917,7 +917,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->hdr, node_cap * n * sizeof(NodeHdr));
     NEED(b->edges, edge_cap * n * sizeof(Edge));
     NEED(b->node_top, n * 4); NEED(b->edge_top, n * 4); NEED(b->leaf, n * 4);
-    NEED(b->kind, n); NEED(b->rvalue, n); NEED(b->fault, n);
+    NEED(b->kind, n); NEED(b->fault, n);
     NEED(b->stats, sizeof(unsigned long long) * ST_COUNT);
     const size_t k = b->spec_k;
     NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * arena_quads(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
@@ -926,7 +926,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->ulog_e, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoE)); NEED(b->ulog_h, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoH));
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
-    b->mem.kind = (uint8_t*)b->kind.p; b->mem.rvalue = (int8_t*)b->rvalue.p; b->mem.fault = (uint8_t*)b->fault.p;
+    b->mem.kind = (uint8_t*)b->kind.p; b->mem.fault = (uint8_t*)b->fault.p;
     b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p; b->mem.spec_meta = (uint32_t*)b->spec_meta.p;
     b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
     b->mem.spec_node = (uint32_t*)b->spec_node.p; b->mem.spec_ord = (uint32_t*)b->spec_ord.p; b->mem.spec_first = (uint32_t*)b->spec_first.p;

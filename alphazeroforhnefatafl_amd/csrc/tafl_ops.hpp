@@ -81,7 +81,6 @@ struct MctsMem {
     uint32_t* edge_top;          // [G]
     uint32_t* leaf;              // [G] leaf of the simulation whose playout value is pending
     uint8_t* kind;               // [G] 0 nothing pending, 1 rollout value pending, 2 terminal value pending
-    int8_t* rvalue;              // [G] playout value handed to the backup
     uint8_t* fault;              // [G]
     // ---- simulation pipeline (DESIGN.md "speculative playout slots") ------------------------------------------
     // Slot j of game g is the playout keyed by simulation index spec_first[g] + j.  Slot 0 is the leaf of the pending real
@@ -338,44 +337,108 @@ struct Ops {
         h.term = term_code(root); h.expanded = 0; h._pad[0] = h._pad[1] = 0;
         M.hdr[g] = h;
         IO::store_rec(M.node_state + (size_t)g * IO::QUADS, root);
-        M.node_top[g] = 1; M.edge_top[g] = 0; M.leaf[g] = 0; M.kind[g] = 0; M.rvalue[g] = 0; M.fault[g] = 0;
+        M.node_top[g] = 1; M.edge_top[g] = 0; M.leaf[g] = 0; M.kind[g] = 0; M.fault[g] = 0;
         M.sim_next[g] = 0; M.spec_n[g] = 0; M.spec_first[g] = 0; M.spec_w[g] = (uint8_t)(M.spec_k > 0 ? M.spec_k - 1 : 0);
         for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;
     }
 
     // Q / N update of one edge with the value v seen from the edge's owner (mcts.py:127-133)
-    static TAFL_HD void edge_update(Edge* e, double v) {
-        if (e->n > 0) { e->q = ((double)e->n * e->q + v) / (double)(e->n + 1); e->n += 1; }   // mcts.py:127-129
-        else { e->q = v; e->n = 1; }                                                            // mcts.py:131-133
+    static TAFL_HD void edge_update(Edge& e, double v) {
+        if (e.n > 0) { e.q = ((double)e.n * e.q + v) / (double)(e.n + 1); e.n += 1; }   // mcts.py:127-129
+        else { e.q = v; e.n = 1; }                                                      // mcts.py:131-133
     }
 
-    // backup of the pending simulation (mcts.py:127-136 unwound iteratively)
-    static TAFL_HD void mcts_backup(const MctsMem& M, uint32_t g) {
-        const uint8_t kind = M.kind[g];
-        if (kind == 0) return;
-        uint32_t cur = M.leaf[g];
+    // ---- one tree step keeps what it touches again and again in registers ------------------------------------------------------------
+    // The tree phase is a chain of dependent memory round trips (one wave per 64 games, nothing to hide them behind), so a value that is
+    // already in a register is never fetched again: the per-game counters, the root header and the sign bits of the root's Qsa live in
+    // StepCtx for the whole step (write-through: memory is always current), a simulation hands its leaf, parent and edge to its backup
+    // (SimOut) instead of passing them through M.leaf / M.kind, and the slot a simulation may consume is fetched beside its selection
+    // (SlotView).  Same arithmetic in the same order as before: results are unchanged.
+    struct RootCache {
+        uint32_t hw[8];              // header of node 0 as eight plain words (scalars: the cache must stay in registers)
+        uint32_t pos[4];             // bit e: Qsa of root edge e (e < 128) is > 0 (puct_pick's shortcut only looks at those)
+        bool pos_valid;
+    };
+    static_assert(sizeof(NodeHdr) == 32, "NodeHdr is eight words");
+    struct StepCtx { uint32_t node_top, edge_top; RootCache rc; };
+    struct SlotView { bool valid; uint8_t kind, reason; int8_t value; uint32_t node, ord, meta, plies; };
+    struct SimOut {
+        uint32_t leaf; uint8_t kind, term;    // kind: 0 fault, 1 playout needed, 2 terminal
+        bool fresh;                  // the leaf was created by this simulation: its edge is new (Nsa = 0) and the fields below are valid
+        uint32_t parent, pslot, eidx;
+        NodeHdr ph;                  // the parent's header after the expansion
+    };
+
+    // (values, never addresses, are selected between the cache and memory: a pointer that may be private or global would put the
+    // cache into scratch memory)
+    static TAFL_HD NodeHdr hdr_get(const MctsMem& M, uint32_t g, uint32_t node, const StepCtx& X) {
+        uint32_t w[8];
+        TAFL_UNROLL for (int i = 0; i < 8; ++i) w[i] = X.rc.hw[i];
+        if (node != 0) {
+            const Quad* p = (const Quad*)&M.hdr[(size_t)node * M.G + g];
+            const Quad a = p[0], b = p[1];
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        }
+        NodeHdr h; __builtin_memcpy(&h, w, sizeof h);
+        return h;
+    }
+    static TAFL_HD void hdr_put(const MctsMem& M, uint32_t g, uint32_t node, const NodeHdr& h, StepCtx& X) {
+        uint32_t w[8]; __builtin_memcpy(w, &h, sizeof h);
+        Quad* p = (Quad*)&M.hdr[(size_t)node * M.G + g];
+        Quad a, b; a.x = w[0]; a.y = w[1]; a.z = w[2]; a.w = w[3]; b.x = w[4]; b.y = w[5]; b.z = w[6]; b.w = w[7];
+        p[0] = a; p[1] = b;
+        TAFL_UNROLL for (int i = 0; i < 8; ++i) X.rc.hw[i] = node == 0 ? w[i] : X.rc.hw[i];
+    }
+    static TAFL_HD void root_load(const MctsMem& M, uint32_t g, StepCtx& X) {
+        const Quad* p = (const Quad*)&M.hdr[g];
+        const Quad a = p[0], b = p[1];
+        X.rc.hw[0] = a.x; X.rc.hw[1] = a.y; X.rc.hw[2] = a.z; X.rc.hw[3] = a.w; X.rc.hw[4] = b.x; X.rc.hw[5] = b.y; X.rc.hw[6] = b.z; X.rc.hw[7] = b.w;
+    }
+    // edge `slot` of node `node` now has Qsa q
+    static TAFL_HD void pos_note(StepCtx& X, uint32_t node, uint32_t slot, double q) {
+        if (node != 0 || !X.rc.pos_valid) return;
+        if (slot >= 128u) { X.rc.pos_valid = false; return; }
+        const uint32_t b = 1u << (slot & 31u), wi = slot >> 5;
+        TAFL_UNROLL for (uint32_t i = 0; i < 4; ++i) { const uint32_t w = X.rc.pos[i]; X.rc.pos[i] = i == wi ? (q > 0.0 ? (w | b) : (w & ~b)) : w; }
+    }
+
+    // backup of one simulation (mcts.py:127-136 unwound iteratively); value: the playout's result for kind 1
+    static TAFL_HD void mcts_backup(const MctsMem& M, uint32_t g, const SimOut& o, int value, StepCtx& X) {
+        if (o.kind == 0) return;
+        uint32_t cur = o.leaf;
         double v;
-        if (kind == 1) {                                        // leaf was expanded by a playout: return -v (mcts.py:100-102)
-            NodeHdr* lh = &M.hdr[(size_t)cur * M.G + g];
-            lh->expanded = 1; lh->ns = (M.flags & TAFL_MCTS_FLAG_FPU_INF) ? 1u : 0u;      // mcts.py:100-101 / mcts.rs:187
-            v = -(double)M.rvalue[g];
+        if (o.kind == 1) {                                      // leaf was expanded by a playout: return -v (mcts.py:100-102)
+            const uint32_t ns0 = (M.flags & TAFL_MCTS_FLAG_FPU_INF) ? 1u : 0u;                     // mcts.py:100-101 / mcts.rs:187
+            if (cur == 0) { NodeHdr rh = hdr_get(M, g, 0, X); rh.expanded = 1; rh.ns = ns0; hdr_put(M, g, 0, rh, X); }
+            else { NodeHdr* lh = &M.hdr[(size_t)cur * M.G + g]; lh->expanded = 1; lh->ns = ns0; }
+            v = -(double)value;
         } else {
-            v = -term_value(M.hdr[(size_t)cur * M.G + g].term); // terminal: return -Es[s] (mcts.py:79-81)
+            v = -term_value(o.term);                            // terminal: return -Es[s] (mcts.py:79-81)
+        }
+        if (cur != 0 && o.fresh) {                              // the new edge: Nsa = 0, so Qsa = v, Nsa = 1 (mcts.py:131-133)
+            Edge e; e.q = v; e.n = 1; e.child = cur;
+            M.edges[(size_t)g * M.edge_cap + o.eidx] = e;
+            pos_note(X, o.parent, o.pslot, v);
+            NodeHdr ph = o.ph; ph.ns += 1;                                                          // mcts.py:135
+            hdr_put(M, g, o.parent, ph, X);
+            v = -v; cur = o.parent;                                                                 // mcts.py:136
         }
         while (cur != 0) {
             const NodeHdr ch = M.hdr[(size_t)cur * M.G + g];
-            NodeHdr* ph = &M.hdr[(size_t)ch.parent * M.G + g];
-            edge_update(&M.edges[(size_t)g * M.edge_cap + ph->edge_base + ch.pslot], v);
-            ph->ns += 1;                                                                            // mcts.py:135
+            NodeHdr ph = hdr_get(M, g, ch.parent, X);
+            Edge* ep = &M.edges[(size_t)g * M.edge_cap + ph.edge_base + ch.pslot];
+            Edge e = *ep; edge_update(e, v); *ep = e;
+            pos_note(X, ch.parent, ch.pslot, e.q);
+            ph.ns += 1;                                                                             // mcts.py:135
+            hdr_put(M, g, ch.parent, ph, X);
             v = -v;                                                                                 // mcts.py:136
             cur = ch.parent;
         }
-        M.kind[g] = 0;
     }
 
     // the action with the highest upper confidence bound (mcts.py:104-119) among the visited children (a prefix of the canonical
     // legal list) and the next unvisited one: returns its index in [0, h.m] (h.m = expand the next unvisited child), -1 if none.
-    static TAFL_HD int puct_pick(const MctsMem& M, uint32_t g, const NodeHdr& h, double c_puct) {
+    static TAFL_HD int puct_pick(const MctsMem& M, uint32_t g, uint32_t node, const NodeHdr& h, double c_puct, StepCtx& X) {
         // first-play urgency of src/mcts.rs:49-51: an unvisited action scores +infinity, the lowest index among them wins
         if ((M.flags & TAFL_MCTS_FLAG_FPU_INF) && h.m < h.n_legal) return (int)h.m;
         const double p = 1.0 / (double)h.n_legal;
@@ -388,16 +451,26 @@ struct Ops {
             // visited one (Nsa >= 1), so a visited action with Qsa <= 0 can neither win nor tie: only the (few) actions with Qsa > 0 are
             // evaluated, in ascending order as mcts.py does - the float64 division is the expensive part of this loop and 64 games share
             // an instruction stream (-24 % VALU instructions in k_mcts_tree).  Same argmax, same tie rule.
+            // At the root the sign bits come from the step's cache (scanned once per step, kept current by every backup).
             const double u0 = cp * sqrt((double)h.ns + TAFL_MCTS_EPS);
+            const bool cacheable = node == 0 && h.m <= 128u;
+            const bool cached = cacheable && X.rc.pos_valid;
+            uint32_t seen[4] = {0u, 0u, 0u, 0u};
             for (uint32_t j0 = 0; j0 < h.m; j0 += 32) {
                 uint32_t pos = 0;
                 const uint32_t lim = h.m - j0 < 32u ? h.m - j0 : 32u;
-                // eight independent loads in flight per step (one load and one wait per edge made this scan the longest dependent
-                // chain of the tree phase: every wait is a trip to L2 / HBM)
-                for (uint32_t t0 = 0; t0 < lim; t0 += 8) {
-                    double q[8];
-                    TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) q[t] = eb[j0 + (t0 + t < lim ? t0 + t : lim - 1u)].q;
-                    TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) pos |= ((t0 + t < lim && q[t] > 0.0) ? 1u : 0u) << (t0 + t);
+                if (cached) {
+                    const uint32_t wi = j0 >> 5;
+                    pos = wi == 0 ? X.rc.pos[0] : wi == 1 ? X.rc.pos[1] : wi == 2 ? X.rc.pos[2] : X.rc.pos[3];
+                } else {
+                    // eight independent loads in flight per step (one load and one wait per edge made this scan the longest dependent
+                    // chain of the tree phase: every wait is a trip to L2 / HBM)
+                    for (uint32_t t0 = 0; t0 < lim; t0 += 8) {
+                        double q[8];
+                        TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) q[t] = eb[j0 + (t0 + t < lim ? t0 + t : lim - 1u)].q;
+                        TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) pos |= ((t0 + t < lim && q[t] > 0.0) ? 1u : 0u) << (t0 + t);
+                    }
+                    if (cacheable) { const uint32_t wi = j0 >> 5; TAFL_UNROLL for (uint32_t i = 0; i < 4; ++i) seen[i] = i == wi ? pos : seen[i]; }
                 }
                 while (pos) {
                     const uint32_t t = (uint32_t)__builtin_ctz(pos);
@@ -407,6 +480,7 @@ struct Ops {
                     if (u > cur_best) { cur_best = u; best = (int)(j0 + t); }
                 }
             }
+            if (cacheable && !cached) { TAFL_UNROLL for (uint32_t i = 0; i < 4; ++i) X.rc.pos[i] = seen[i]; X.rc.pos_valid = true; }
             if (u0 > cur_best) { cur_best = u0; best = (int)h.m; }
             return best;
         }
@@ -437,63 +511,65 @@ struct Ops {
         }
     }
 
-    // select + expand of simulation number `sim` (mcts.py:77-123).  Leaves M.leaf/M.kind set for the rollout + backup.
-    static TAFL_HD void mcts_select_expand(const MctsMem& M, uint32_t g, uint32_t sim, double c_puct, const K& C, LaneStats& ls) {
+    // selection of one simulation (mcts.py:77-119): walks down to a node that ends the simulation (o.kind 0 fault, 1 unexpanded node,
+    // 2 terminal node) or to the node whose next unvisited child has to be created (o.kind 4: o.parent = that node, o.ph = its header,
+    // o.pslot = the child's ordinal)
+    static TAFL_HD void mcts_select(const MctsMem& M, uint32_t g, double c_puct, LaneStats& ls, StepCtx& X, SimOut& o) {
         uint32_t cur = 0;
         ls.sims += 1;
+        o.fresh = false; o.term = 0; o.parent = 0; o.pslot = 0; o.eidx = 0;
         for (uint32_t depth = 0; depth < M.node_cap + 1; ++depth) {
-            NodeHdr* hp = &M.hdr[(size_t)cur * M.G + g];
-            const NodeHdr h = *hp;
-            if (h.term) { M.leaf[g] = cur; M.kind[g] = 2; ls.terminal_hits += 1; return; }
-            if (!h.expanded) { M.leaf[g] = cur; M.kind[g] = 1; return; }
+            const NodeHdr h = hdr_get(M, g, cur, X);
+            if (h.term) { o.leaf = cur; o.kind = 2; o.term = h.term; ls.terminal_hits += 1; return; }
+            if (!h.expanded) { o.leaf = cur; o.kind = 1; return; }
             ls.depth += 1;
-            const int best = puct_pick(M, g, h, c_puct);
+            const int best = puct_pick(M, g, cur, h, c_puct, X);
             ls.scanned += h.m;
-            const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
-            if (best < 0) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
-            if ((uint32_t)best < h.m) { cur = eb[best].child; continue; }
-            // ---- expand edge h.m: getNextState (mcts.py:122-123) -------------------------------------------
-            // If the slot of this simulation index was prepared for exactly this child (same node, same ordinal), its state, play and
-            // legal-play count are already there: no second canon_next / apply.
-            S st; Move mv; Moves<NL> nx;
-            const uint32_t sj = sim - M.spec_first[g];
-            const size_t so = (size_t)(sj < M.spec_k ? sj : 0) * M.G + g;
-            const bool prepared = sj >= 1 && sj < (uint32_t)M.spec_n[g] && M.spec_kind[so] >= 1 && M.spec_node[so] == cur && M.spec_ord[so] == h.m;
-            if (prepared) {
-                IO::load_rec(M.spec_state + so * IO::QUADS, st);
-                const uint32_t meta = M.spec_meta[so];
-                mv.from = meta & 0xFFu; mv.dir = (meta >> 8) & 3u; mv.dist = (meta >> 10) & 0x3Fu; mv.to = 0; nx.total = meta >> 16;
-            } else {
-                IO::load_rec(M.node_state + ((size_t)cur * M.G + g) * IO::QUADS, st);
-                mv.from = h.cur_from; mv.to = 0; mv.dir = h.cur_dir; mv.dist = h.cur_dist;
-                if (!E::canon_next(st, st.flags & TAFL_F_SIDE, C, mv)) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
-                E::apply(st, mv, C, nullptr, nx);
-            }
-            const uint32_t id = M.node_top[g];
-            uint32_t base = h.edge_base; uint32_t cap = h.cap;
-            if (h.m == cap) {                                      // grow the edge array (amortised doubling)
-                const uint32_t ncap = cap ? cap * 2u : 4u;
-                const uint32_t nbase = M.edge_top[g];
-                if (id >= M.node_cap || nbase + ncap > M.edge_cap) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
-                copy_edges(&M.edges[(size_t)g * M.edge_cap + nbase], eb, h.m);
-                M.edge_top[g] = nbase + ncap; base = nbase; cap = ncap;
-            } else if (id >= M.node_cap) { M.fault[g] = 1; ls.faults += 1; M.leaf[g] = cur; M.kind[g] = 0; return; }
-            Edge ne; ne.q = 0.0; ne.n = 0; ne.child = id;
-            M.edges[(size_t)g * M.edge_cap + base + h.m] = ne;
-            hp->edge_base = base; hp->cap = (uint16_t)cap; hp->m = (uint16_t)(h.m + 1);
-            hp->cur_from = (uint16_t)mv.from; hp->cur_dir = (uint8_t)mv.dir; hp->cur_dist = (uint8_t)mv.dist;
-            NodeHdr nh; nh.parent = cur; nh.edge_base = 0; nh.ns = 0; nh.pslot = h.m; nh.m = 0; nh.n_legal = (uint16_t)nx.total; nh.cap = 0;
-            nh.mv_from = (uint16_t)mv.from; nh.mv_dir = (uint8_t)mv.dir; nh.mv_dist = (uint8_t)mv.dist;
-            nh.cur_from = (uint16_t)TAFL_NO_SQ; nh.cur_dir = 0; nh.cur_dist = 0;
-            nh.term = term_code(st); nh.expanded = 0; nh._pad[0] = nh._pad[1] = 0;
-            M.hdr[(size_t)id * M.G + g] = nh;
-            IO::store_rec(M.node_state + ((size_t)id * M.G + g) * IO::QUADS, st);
-            M.node_top[g] = id + 1;
-            M.leaf[g] = id;
-            if (nh.term) { M.kind[g] = 2; ls.terminal_hits += 1; } else M.kind[g] = 1;
+            if (best < 0) { M.fault[g] = 1; ls.faults += 1; o.leaf = cur; o.kind = 0; return; }
+            if ((uint32_t)best < h.m) { cur = M.edges[(size_t)g * M.edge_cap + h.edge_base + (uint32_t)best].child; continue; }
+            o.leaf = cur; o.kind = 4; o.parent = cur; o.pslot = h.m; o.ph = h;
             return;
         }
-        M.fault[g] = 1; ls.faults += 1; M.kind[g] = 0;
+        M.fault[g] = 1; ls.faults += 1; o.leaf = 0; o.kind = 0;
+    }
+    // child state of the expansion mcts_select asked for, computed from the parent's state: getNextState (mcts.py:122-123)
+    static TAFL_HD bool mcts_child_state(const MctsMem& M, uint32_t g, const SimOut& o, const K& C, S& st, Move& mv, Moves<NL>& nx) {
+        IO::load_rec(M.node_state + ((size_t)o.parent * M.G + g) * IO::QUADS, st);
+        mv.from = o.ph.cur_from; mv.to = 0; mv.dir = o.ph.cur_dir; mv.dist = o.ph.cur_dist;
+        if (!E::canon_next(st, st.flags & TAFL_F_SIDE, C, mv)) return false;
+        E::apply(st, mv, C, nullptr, nx);
+        return true;
+    }
+    // creates the child (state st reached by play mv, nx_total legal plays) the selection asked for: o becomes the simulation's leaf
+    static TAFL_HD void mcts_expand(const MctsMem& M, uint32_t g, LaneStats& ls, StepCtx& X, SimOut& o, const S& st, const Move& mv, uint32_t nx_total) {
+        const uint32_t cur = o.parent;
+        NodeHdr h = o.ph;
+        const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+        const uint32_t id = X.node_top;
+        uint32_t base = h.edge_base; uint32_t cap = h.cap;
+        if (h.m == cap) {                                      // grow the edge array (amortised doubling)
+            const uint32_t ncap = cap ? cap * 2u : 4u;
+            const uint32_t nbase = X.edge_top;
+            if (id >= M.node_cap || nbase + ncap > M.edge_cap) { M.fault[g] = 1; ls.faults += 1; o.leaf = cur; o.kind = 0; return; }
+            copy_edges(&M.edges[(size_t)g * M.edge_cap + nbase], eb, h.m);
+            X.edge_top = nbase + ncap; base = nbase; cap = ncap;
+        } else if (id >= M.node_cap) { M.fault[g] = 1; ls.faults += 1; o.leaf = cur; o.kind = 0; return; }
+        Edge ne; ne.q = 0.0; ne.n = 0; ne.child = id;
+        M.edges[(size_t)g * M.edge_cap + base + h.m] = ne;
+        const uint32_t slot = h.m;
+        h.edge_base = base; h.cap = (uint16_t)cap; h.m = (uint16_t)(slot + 1);
+        h.cur_from = (uint16_t)mv.from; h.cur_dir = (uint8_t)mv.dir; h.cur_dist = (uint8_t)mv.dist;
+        hdr_put(M, g, cur, h, X);
+        pos_note(X, cur, slot, 0.0);
+        NodeHdr nh; nh.parent = cur; nh.edge_base = 0; nh.ns = 0; nh.pslot = (uint16_t)slot; nh.m = 0; nh.n_legal = (uint16_t)nx_total; nh.cap = 0;
+        nh.mv_from = (uint16_t)mv.from; nh.mv_dir = (uint8_t)mv.dir; nh.mv_dist = (uint8_t)mv.dist;
+        nh.cur_from = (uint16_t)TAFL_NO_SQ; nh.cur_dir = 0; nh.cur_dist = 0;
+        nh.term = term_code(st); nh.expanded = 0; nh._pad[0] = nh._pad[1] = 0;
+        M.hdr[(size_t)id * M.G + g] = nh;
+        IO::store_rec(M.node_state + ((size_t)id * M.G + g) * IO::QUADS, st);
+        X.node_top = id + 1;
+        o.leaf = id; o.term = nh.term; o.fresh = true; o.pslot = slot; o.eidx = base + slot; o.ph = h;
+        if (nh.term) { o.kind = 2; ls.terminal_hits += 1; } else o.kind = 1;
     }
 
     // ---- simulation pipeline ----------------------------------------------------------------------------------------
@@ -508,66 +584,69 @@ struct Ops {
     static constexpr uint32_t VIRT_CHILD = 0xFFFFFFFFu;       // child id of an edge that exists only during the speculation pass
     static constexpr uint32_t ORD_SELF = 0xFFFFFFFFu;         // spec_ord of slot 0: the slot's leaf is spec_node itself
 
-    static TAFL_HD void consume_stats(const MctsMem& M, uint32_t g, uint32_t j, LaneStats& ls) {
-        ls.rollouts += 1; ls.rollout_plies += M.spec_plies[(size_t)j * M.G + g]; ls.reason_hist4 += 1ull << (4u * (M.spec_reason[(size_t)j * M.G + g] & 15u));
-    }
-
     struct SpecLog {                                          // undo log of one speculation pass (global memory, per game)
         UndoE* e; UndoH* h; uint32_t ne, nh, cap; bool ok;
     };
-    static TAFL_HD void log_edge(const MctsMem& M, uint32_t g, SpecLog& L, uint32_t eidx) {
+    static TAFL_HD void log_edge(SpecLog& L, uint32_t eidx, const Edge& old) {
         if (L.ne >= L.cap) { L.ok = false; return; }
-        UndoE u; u.idx = eidx; u._pad = 0; u.e = M.edges[(size_t)g * M.edge_cap + eidx];
+        UndoE u; u.idx = eidx; u._pad = 0; u.e = old;
         L.e[L.ne++] = u;
     }
-    static TAFL_HD void log_hdr(const MctsMem& M, uint32_t g, SpecLog& L, uint32_t node) {
+    static TAFL_HD void log_hdr(SpecLog& L, uint32_t node, const NodeHdr& old) {
         if (L.nh >= L.cap) { L.ok = false; return; }
-        UndoH u; u.node = node; u.h = M.hdr[(size_t)node * M.G + g];
+        UndoH u; u.node = node; u.h = old;
         L.h[L.nh++] = u;
     }
-    // assumed backup: edge `eidx` of node `cur` receives v, then the path to the root as in mcts_backup; every touched record is logged
-    static TAFL_HD void spec_backup(const MctsMem& M, uint32_t g, SpecLog& L, uint32_t cur, uint32_t eidx, double v) {
+    // assumed backup: edge `eidx` of node `cur` receives v, then the path to the root as in mcts_backup; every touched record is logged.
+    // new_edge: the edge was created by this pass (Qsa = 0, Nsa = 0, virtual child): nothing to fetch.
+    static TAFL_HD void spec_backup(const MctsMem& M, uint32_t g, SpecLog& L, uint32_t cur, uint32_t eidx, double v, bool new_edge, StepCtx& X) {
         for (uint32_t guard = 0; guard < M.node_cap + 1 && L.ok; ++guard) {
-            log_edge(M, g, L, eidx); log_hdr(M, g, L, cur);
+            NodeHdr ph = hdr_get(M, g, cur, X);
+            Edge* ep = &M.edges[(size_t)g * M.edge_cap + eidx];
+            Edge e;
+            if (new_edge) { e.q = 0.0; e.n = 0; e.child = VIRT_CHILD; } else e = *ep;
+            log_edge(L, eidx, e); log_hdr(L, cur, ph);
             if (!L.ok) return;
-            edge_update(&M.edges[(size_t)g * M.edge_cap + eidx], v);
-            NodeHdr* ph = &M.hdr[(size_t)cur * M.G + g];
-            ph->ns += 1;
+            edge_update(e, v); *ep = e;
+            pos_note(X, cur, eidx - ph.edge_base, e.q);
+            ph.ns += 1;
+            hdr_put(M, g, cur, ph, X);
             if (cur == 0) return;
-            const uint32_t parent = ph->parent, pslot = ph->pslot;
-            eidx = M.hdr[(size_t)parent * M.G + g].edge_base + pslot;
-            cur = parent; v = -v;
+            const uint32_t parent = ph.parent, pslot = ph.pslot;
+            eidx = hdr_get(M, g, parent, X).edge_base + pslot;
+            cur = parent; v = -v; new_edge = false;
         }
     }
     // Predicts the expansions of simulations first+1 .. first+want-1 after the real leaf `L` of simulation `first` became slot 0.
     // Returns the number of slots (placeholders included).  `assumed`: value assumed for a playout in flight, seen from the leaf's mover.
     static TAFL_HD uint32_t mcts_speculate(const MctsMem& M, uint32_t g, uint32_t leaf, uint32_t first, uint32_t want, double c_puct,
-                                           uint32_t n_sims, double assumed, const K& C, LaneStats& ls) {
+                                           uint32_t n_sims, double assumed, const K& C, LaneStats& ls, StepCtx& X) {
         SpecLog L; L.e = M.ulog_e + (size_t)g * M.ulog_cap; L.h = M.ulog_h + (size_t)g * M.ulog_cap; L.ne = L.nh = 0; L.cap = M.ulog_cap; L.ok = true;
-        uint32_t vtop = M.edge_top[g];                            // edge arrays that grow during the pass take free arena space, not committed
+        const RootCache committed = X.rc;                          // the pass ends where it began
+        uint32_t vtop = X.edge_top;                                // edge arrays that grow during the pass take free arena space, not committed
         uint32_t cnt = 1;
         // the pending leaf as it will be once its playout value arrives: expanded, its path updated with the assumed value
         {
-            log_hdr(M, g, L, leaf);
-            NodeHdr* lh = &M.hdr[(size_t)leaf * M.G + g];
-            lh->expanded = 1; lh->ns = (M.flags & TAFL_MCTS_FLAG_FPU_INF) ? 1u : 0u;
+            NodeHdr lh = hdr_get(M, g, leaf, X);
+            log_hdr(L, leaf, lh);
+            if (L.ok) { lh.expanded = 1; lh.ns = (M.flags & TAFL_MCTS_FLAG_FPU_INF) ? 1u : 0u; hdr_put(M, g, leaf, lh, X); }
             if (leaf != 0 && L.ok) {
-                const uint32_t parent = lh->parent;
-                spec_backup(M, g, L, parent, M.hdr[(size_t)parent * M.G + g].edge_base + lh->pslot, -assumed);
+                const uint32_t parent = lh.parent;
+                spec_backup(M, g, L, parent, hdr_get(M, g, parent, X).edge_base + lh.pslot, -assumed, false, X);
             }
         }
         for (uint32_t t = 1; t < want && first + t < n_sims && L.ok; ++t) {
             uint32_t cur = 0; bool stop = false, placed = false;
             for (uint32_t depth = 0; depth < M.node_cap + 1; ++depth) {
-                const NodeHdr h = M.hdr[(size_t)cur * M.G + g];
+                NodeHdr h = hdr_get(M, g, cur, X);
                 if (h.term) {                                     // the simulation ends on a terminal node: its value is exact, no playout
                     if (cur == 0) { stop = true; break; }
-                    spec_backup(M, g, L, h.parent, M.hdr[(size_t)h.parent * M.G + g].edge_base + h.pslot, -term_value(h.term));
+                    spec_backup(M, g, L, h.parent, hdr_get(M, g, h.parent, X).edge_base + h.pslot, -term_value(h.term), false, X);
                     M.spec_kind[(size_t)t * M.G + g] = 0; placed = true;
                     break;
                 }
                 if (!h.expanded) { stop = true; break; }
-                const int best = puct_pick(M, g, h, c_puct);
+                const int best = puct_pick(M, g, cur, h, c_puct, X);
                 if (best < 0) { stop = true; break; }
                 if ((uint32_t)best < h.m) {
                     const uint32_t child = M.edges[(size_t)g * M.edge_cap + h.edge_base + (uint32_t)best].child;
@@ -581,7 +660,7 @@ struct Ops {
                 Moves<NL> nx;
                 E::apply(cst, mv, C, nullptr, nx);
                 uint32_t base = h.edge_base, cap = h.cap;
-                log_hdr(M, g, L, cur);
+                log_hdr(L, cur, h);
                 if (!L.ok) { stop = true; break; }
                 if (h.m == cap) {                                 // uncommitted growth into free arena space
                     const uint32_t ncap = cap ? cap * 2u : 4u;
@@ -591,25 +670,27 @@ struct Ops {
                 }
                 Edge ne; ne.q = 0.0; ne.n = 0; ne.child = VIRT_CHILD;
                 M.edges[(size_t)g * M.edge_cap + base + h.m] = ne;
-                NodeHdr* hp = &M.hdr[(size_t)cur * M.G + g];
-                hp->edge_base = base; hp->cap = (uint16_t)cap; hp->m = (uint16_t)(h.m + 1);
-                hp->cur_from = (uint16_t)mv.from; hp->cur_dir = (uint8_t)mv.dir; hp->cur_dist = (uint8_t)mv.dist;
+                const uint32_t slot = h.m;
+                h.edge_base = base; h.cap = (uint16_t)cap; h.m = (uint16_t)(slot + 1);
+                h.cur_from = (uint16_t)mv.from; h.cur_dir = (uint8_t)mv.dir; h.cur_dist = (uint8_t)mv.dist;
+                hdr_put(M, g, cur, h, X);
+                pos_note(X, cur, slot, 0.0);
                 const uint8_t tc = term_code(cst);
                 const size_t so = (size_t)t * M.G + g;
                 IO::store_rec(M.spec_state + so * IO::QUADS, cst);
                 M.spec_meta[so] = mv.from | (mv.dir << 8) | (mv.dist << 10) | (nx.total << 16);
-                M.spec_node[so] = cur; M.spec_ord[so] = h.m;
+                M.spec_node[so] = cur; M.spec_ord[so] = slot;
                 M.spec_kind[so] = tc ? 3 : 1;
                 if (!tc) ls.spec_issued += 1;
                 placed = true;
-                spec_backup(M, g, L, cur, base + h.m, tc ? -term_value(tc) : -assumed);
+                spec_backup(M, g, L, cur, base + slot, tc ? -term_value(tc) : -assumed, true, X);
                 break;
             }
             if (stop || !placed) break;
             cnt = t + 1;
         }
-        // restore the tree (reverse order: a record may have been logged more than once)
-        // (the records are fetched four at a time, the stores keep their order)
+        // restore the tree (reverse order: a record may have been logged more than once; the records are fetched four at a time, the
+        // stores keep their order)
         for (uint32_t i = L.ne; i > 0; i -= (i < 4u ? i : 4u)) {
             UndoE u[4];
             TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) u[t] = L.e[t < i ? i - 1u - t : 0u];
@@ -620,6 +701,7 @@ struct Ops {
             TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) u[t] = L.h[t < i ? i - 1u - t : 0u];
             TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) if (t < i) M.hdr[(size_t)u[t].node * M.G + g] = u[t].h;
         }
+        X.rc = committed;
         return cnt;
     }
 
@@ -631,39 +713,82 @@ struct Ops {
     // wcap: most predicted simulations a game may run beside the pending one (the host lowers it while few predictions come true: a
     // prediction costs a child expansion in the tree phase whether it is consumed or not).
     static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, uint32_t wcap, const K& C, LaneStats& ls) {
+        // everything the step needs from the per-game arrays, fetched side by side
         uint32_t sim = M.sim_next[g];
-        if (M.kind[g] == 1) {                                    // slot 0 of the previous call
-            if (M.spec_kind[g] != 2) return;                     // its playout has not run yet (the round was full): the slots stay requested
-            M.rvalue[g] = M.spec_value[g];
-            consume_stats(M, g, 0, ls);
-            mcts_backup(M, g); ++sim;
-        }
+        const uint8_t kind0 = M.kind[g];
+        const uint32_t leaf0 = M.leaf[g];
         const uint32_t had = M.spec_n[g], first = M.spec_first[g];
+        const uint32_t w0 = M.spec_w[g];
+        StepCtx X; X.node_top = M.node_top[g]; X.edge_top = M.edge_top[g];
+        root_load(M, g, X); X.rc.pos_valid = false; TAFL_UNROLL for (uint32_t i = 0; i < 4; ++i) X.rc.pos[i] = 0;
+        const uint8_t sk0 = M.spec_kind[g], sr0 = M.spec_reason[g]; const int8_t sv0 = M.spec_value[g]; const uint32_t sp0 = M.spec_plies[g];
+        if (kind0 == 1) {                                        // slot 0 of the previous call
+            if (sk0 != 2) return;                                // its playout has not run yet (the round was full): the slots stay requested
+            ls.rollouts += 1; ls.rollout_plies += sp0; ls.reason_hist4 += 1ull << (4u * (sr0 & 15u));
+            SimOut o; o.leaf = leaf0; o.kind = 1; o.term = 0; o.fresh = false; o.parent = 0; o.pslot = 0; o.eidx = 0;
+            mcts_backup(M, g, o, (int)sv0, X); ++sim;
+        }
         uint32_t hits = 0;
+        bool pending = false; uint32_t pend_leaf = leaf0;
+        // The games of a wave take different numbers of turns through the inner loop, so it holds only what is cheap (selection, an
+        // expansion whose state a slot has prepared, backup).  An expansion that needs canon_next + apply (no slot, or the prediction
+        // failed) leaves it and is computed behind it, once per wave; the game then waits for that leaf's playout, and only a terminal
+        // child sends it round again.
         for (;;) {
-            if (sim >= n_sims) { M.spec_n[g] = 0; break; }
-            mcts_select_expand(M, g, sim, c_puct, C, ls);
-            const uint8_t kind = M.kind[g];
-            if (kind == 0) { ++sim; continue; }                                     // fault (flagged per game): nothing to back up
-            if (kind == 2) { mcts_backup(M, g); ++sim; continue; }                  // terminal node: value known at once
-            const uint32_t L = M.leaf[g];
-            const uint32_t j = sim - first;
-            if (L != 0 && had > 0 && sim > first && j < had) {
-                const NodeHdr lh = M.hdr[(size_t)L * M.G + g];
-                const size_t so = (size_t)j * M.G + g;
-                if (M.spec_kind[so] == 2 && M.spec_node[so] == lh.parent && M.spec_ord[so] == (uint32_t)lh.pslot) {
-                    M.rvalue[g] = M.spec_value[so];                               // predicted expansion: reuse its playout
-                    consume_stats(M, g, j, ls); ls.spec_hits += 1; ++hits;
-                    mcts_backup(M, g); ++sim;
-                    continue;
+            bool deferred = false;
+            SimOut o;
+            for (;;) {
+                if (sim >= n_sims) break;
+                // the slot issued for this simulation index (if any), fetched beside the selection
+                const uint32_t j = sim - first;
+                SlotView sv; sv.valid = had > 0 && sim > first && j < had;
+                const size_t so = (size_t)(sv.valid ? j : 0u) * M.G + g;
+                sv.kind = M.spec_kind[so]; sv.node = M.spec_node[so]; sv.ord = M.spec_ord[so]; sv.meta = M.spec_meta[so];
+                sv.value = M.spec_value[so]; sv.plies = M.spec_plies[so]; sv.reason = M.spec_reason[so];
+                mcts_select(M, g, c_puct, ls, X, o);
+                if (o.kind == 4) {
+                    // If the slot of this simulation index was prepared for exactly this child (same node, same ordinal), its state, play
+                    // and legal-play count are already there: no second canon_next / apply.
+                    if (!(sv.valid && sv.kind >= 1 && sv.node == o.parent && sv.ord == o.pslot)) { deferred = true; break; }
+                    S st; IO::load_rec(M.spec_state + so * IO::QUADS, st);
+                    Move mv; mv.from = sv.meta & 0xFFu; mv.dir = (sv.meta >> 8) & 3u; mv.dist = (sv.meta >> 10) & 0x3Fu; mv.to = 0;
+                    mcts_expand(M, g, ls, X, o, st, mv, sv.meta >> 16);
                 }
+                if (o.kind == 0) { ++sim; continue; }                                   // fault (flagged per game): nothing to back up
+                if (o.kind == 2) { mcts_backup(M, g, o, 0, X); ++sim; continue; }       // terminal node: value known at once
+                const uint32_t L = o.leaf;
+                if (L != 0 && sv.valid && sv.kind == 2) {
+                    uint32_t lp = o.parent, lo = o.pslot;
+                    if (!o.fresh) { const NodeHdr lh = M.hdr[(size_t)L * M.G + g]; lp = lh.parent; lo = lh.pslot; }
+                    if (sv.node == lp && sv.ord == lo) {                                // predicted expansion: reuse its playout
+                        ls.rollouts += 1; ls.rollout_plies += sv.plies; ls.reason_hist4 += 1ull << (4u * (sv.reason & 15u));
+                        ls.spec_hits += 1; ++hits;
+                        mcts_backup(M, g, o, (int)sv.value, X); ++sim;
+                        continue;
+                    }
+                }
+                pending = true; pend_leaf = L;
+                break;                                                                  // wait for the playouts
             }
-            // issue new slots: slot 0 = this leaf, slots 1.. = the predicted expansions of the following simulations
+            if (!deferred) break;
+            S st; Move mv; Moves<NL> nx;
+            if (!mcts_child_state(M, g, o, C, st, mv, nx)) { M.fault[g] = 1; ls.faults += 1; ++sim; continue; }
+            mcts_expand(M, g, ls, X, o, st, mv, nx.total);
+            if (o.kind == 1) { pending = true; pend_leaf = o.leaf; break; }
+            if (o.kind == 2) mcts_backup(M, g, o, 0, X);
+            ++sim;
+        }
+        if (!pending) M.spec_n[g] = 0;
+        // Issue new slots: slot 0 = the waiting leaf, slots 1.. = the predicted expansions of the following simulations.  This sits BEHIND
+        // the loop on purpose: the games of a wave leave the loop after different numbers of consumed slots, and inside the loop the wave
+        // would run the prediction pass (the most expensive code of the step) once per distinct count instead of once.
+        if (pending) {
+            const uint32_t L = pend_leaf;
             S lst; IO::load_rec(M.node_state + ((size_t)L * M.G + g) * IO::QUADS, lst);
             IO::store_rec(M.spec_state + (size_t)g * IO::QUADS, lst);
             M.spec_kind[g] = 1; M.spec_node[g] = L; M.spec_ord[g] = ORD_SELF;
             // width: what the last issue showed to be predictable (+1), capped by the slots that exist and by the deadline
-            uint32_t w = M.spec_w[g];
+            uint32_t w = w0;
             if (had > 1) {
                 uint32_t issued = 0;
                 uint8_t sk[kMctsMaxSlots];
@@ -693,12 +818,12 @@ struct Ops {
             } else if (rounds_left == 0 && want > w + 1) want = w + 1;
             if (want > M.spec_k) want = M.spec_k;
             uint32_t cnt = 1;
-            if (want > 1 && sim + 1 < n_sims && M.ulog_cap > 0) cnt = mcts_speculate(M, g, L, sim, want, c_puct, n_sims, 0.0, C, ls);
+            if (want > 1 && sim + 1 < n_sims && M.ulog_cap > 0) cnt = mcts_speculate(M, g, L, sim, want, c_puct, n_sims, 0.0, C, ls, X);
             for (uint32_t t = cnt; t < M.spec_k; ++t) M.spec_kind[(size_t)t * M.G + g] = 0;
             M.spec_n[g] = (uint8_t)cnt; M.spec_first[g] = sim;
-            break;                                                                  // wait for the playouts
         }
-        M.sim_next[g] = sim;
+        M.sim_next[g] = sim; M.node_top[g] = X.node_top; M.edge_top[g] = X.edge_top;
+        M.leaf[g] = pend_leaf; M.kind[g] = pending ? 1 : 0;
     }
 
     // playout of slot j of game g (predict() of mcts.py:85 in random-rollout mode)

@@ -86,10 +86,10 @@ struct Host {
         std::vector<Edge> edges((size_t)M.edge_cap * G);
         std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sfirst(G), splies((size_t)M.spec_k * G), smeta((size_t)M.spec_k * G), snode((size_t)M.spec_k * G), sord((size_t)M.spec_k * G);
         std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), sw(G);
-        std::vector<int8_t> rv(G), sval((size_t)M.spec_k * G);
+        std::vector<int8_t> sval((size_t)M.spec_k * G);
         std::vector<UndoE> ue((size_t)(M.ulog_cap ? M.ulog_cap : 1) * G); std::vector<UndoH> uh((size_t)(M.ulog_cap ? M.ulog_cap : 1) * G);
         M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
-        M.leaf = leaf.data(); M.kind = kind.data(); M.rvalue = rv.data(); M.fault = fault.data();
+        M.leaf = leaf.data(); M.kind = kind.data(); M.fault = fault.data();
         M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data(); M.spec_meta = smeta.data();
         M.spec_plies = splies.data(); M.spec_node = snode.data(); M.spec_ord = sord.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_w = sw.data();
         M.ulog_e = ue.data(); M.ulog_h = uh.data();
