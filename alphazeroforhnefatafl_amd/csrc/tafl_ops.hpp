@@ -636,9 +636,12 @@ struct Ops {
             }
         }
         for (uint32_t t = 1; t < want && first + t < n_sims && L.ok; ++t) {
-            uint32_t cur = 0; bool stop = false, placed = false;
+            // the selection walks down in a loop of its own: games of a wave stop at different depths, and the expansion below (the
+            // expensive part) must run once for all of them, not once per depth
+            uint32_t cur = 0; bool stop = false, placed = false, expand = false;
+            NodeHdr h;
             for (uint32_t depth = 0; depth < M.node_cap + 1; ++depth) {
-                NodeHdr h = hdr_get(M, g, cur, X);
+                h = hdr_get(M, g, cur, X);
                 if (h.term) {                                     // the simulation ends on a terminal node: its value is exact, no playout
                     if (cur == 0) { stop = true; break; }
                     spec_backup(M, g, L, h.parent, hdr_get(M, g, h.parent, X).edge_base + h.pslot, -term_value(h.term), false, X);
@@ -653,38 +656,48 @@ struct Ops {
                     if (child == VIRT_CHILD) { stop = true; break; }   // would descend into a leaf that exists only as a slot
                     cur = child; continue;
                 }
+                expand = true;
+                break;
+            }
+            if (expand) {
                 // predicted expansion: child number h.m of node cur
                 S cst; IO::load_rec(M.node_state + ((size_t)cur * M.G + g) * IO::QUADS, cst);
                 Move mv; mv.from = h.cur_from; mv.to = 0; mv.dir = h.cur_dir; mv.dist = h.cur_dist;
-                if (!E::canon_next(cst, cst.flags & TAFL_F_SIDE, C, mv)) { stop = true; break; }
                 Moves<NL> nx;
-                E::apply(cst, mv, C, nullptr, nx);
-                uint32_t base = h.edge_base, cap = h.cap;
-                log_hdr(L, cur, h);
-                if (!L.ok) { stop = true; break; }
-                if (h.m == cap) {                                 // uncommitted growth into free arena space
-                    const uint32_t ncap = cap ? cap * 2u : 4u;
-                    if (vtop + ncap > M.edge_cap) { stop = true; break; }
-                    copy_edges(&M.edges[(size_t)g * M.edge_cap + vtop], &M.edges[(size_t)g * M.edge_cap + base], h.m);
-                    base = vtop; cap = ncap; vtop += ncap;
+                bool ok = E::canon_next(cst, cst.flags & TAFL_F_SIDE, C, mv);
+                if (ok) {
+                    E::apply(cst, mv, C, nullptr, nx);
+                    log_hdr(L, cur, h);
+                    ok = L.ok;
                 }
-                Edge ne; ne.q = 0.0; ne.n = 0; ne.child = VIRT_CHILD;
-                M.edges[(size_t)g * M.edge_cap + base + h.m] = ne;
-                const uint32_t slot = h.m;
-                h.edge_base = base; h.cap = (uint16_t)cap; h.m = (uint16_t)(slot + 1);
-                h.cur_from = (uint16_t)mv.from; h.cur_dir = (uint8_t)mv.dir; h.cur_dist = (uint8_t)mv.dist;
-                hdr_put(M, g, cur, h, X);
-                pos_note(X, cur, slot, 0.0);
-                const uint8_t tc = term_code(cst);
-                const size_t so = (size_t)t * M.G + g;
-                IO::store_rec(M.spec_state + so * IO::QUADS, cst);
-                M.spec_meta[so] = mv.from | (mv.dir << 8) | (mv.dist << 10) | (nx.total << 16);
-                M.spec_node[so] = cur; M.spec_ord[so] = slot;
-                M.spec_kind[so] = tc ? 3 : 1;
-                if (!tc) ls.spec_issued += 1;
-                placed = true;
-                spec_backup(M, g, L, cur, base + slot, tc ? -term_value(tc) : -assumed, true, X);
-                break;
+                uint32_t base = h.edge_base, cap = h.cap;
+                if (ok && h.m == cap) {                           // uncommitted growth into free arena space
+                    const uint32_t ncap = cap ? cap * 2u : 4u;
+                    if (vtop + ncap > M.edge_cap) ok = false;
+                    else {
+                        copy_edges(&M.edges[(size_t)g * M.edge_cap + vtop], &M.edges[(size_t)g * M.edge_cap + base], h.m);
+                        base = vtop; cap = ncap; vtop += ncap;
+                    }
+                }
+                if (!ok) stop = true;
+                else {
+                    Edge ne; ne.q = 0.0; ne.n = 0; ne.child = VIRT_CHILD;
+                    M.edges[(size_t)g * M.edge_cap + base + h.m] = ne;
+                    const uint32_t slot = h.m;
+                    h.edge_base = base; h.cap = (uint16_t)cap; h.m = (uint16_t)(slot + 1);
+                    h.cur_from = (uint16_t)mv.from; h.cur_dir = (uint8_t)mv.dir; h.cur_dist = (uint8_t)mv.dist;
+                    hdr_put(M, g, cur, h, X);
+                    pos_note(X, cur, slot, 0.0);
+                    const uint8_t tc = term_code(cst);
+                    const size_t so = (size_t)t * M.G + g;
+                    IO::store_rec(M.spec_state + so * IO::QUADS, cst);
+                    M.spec_meta[so] = mv.from | (mv.dir << 8) | (mv.dist << 10) | (nx.total << 16);
+                    M.spec_node[so] = cur; M.spec_ord[so] = slot;
+                    M.spec_kind[so] = tc ? 3 : 1;
+                    if (!tc) ls.spec_issued += 1;
+                    placed = true;
+                    spec_backup(M, g, L, cur, base + slot, tc ? -term_value(tc) : -assumed, true, X);
+                }
             }
             if (stop || !placed) break;
             cnt = t + 1;
