@@ -11,6 +11,10 @@ python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1
 echo "kt done"
+# the same kernel trace for the headline workload alone (no variants): its per-kernel averages are the ones to compare with the HIP-event
+# averages in that run's own bench line
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_headline -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-variants > $O/kt_headline.log 2>&1
+echo "kt headline done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-variants > $O/fetch.log 2>&1
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-variants > $O/write.log 2>&1
