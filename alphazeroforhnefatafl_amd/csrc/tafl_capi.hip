@@ -1024,7 +1024,7 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     // tree phase of a partition (latency- and divergence-bound, one wave per 64 games) then runs under the playouts of the others instead
     // of on an idle device, and the partitions' rounds interleave instead of ending together.  Each partition may fill its share of the
     // device.  Small batches stay in one piece.
-    uint32_t parts = n >= 8192u ? 2u : 1u;                      // measured at 65 536 games, S = 64: 1: 52.3, 2: 60.6, 4: 57.3, 8: 35.7 M sims/s
+    uint32_t parts = n >= 8192u ? 2u : 1u;                      // measured at 65 536 games, S = 64: 1: 56.9, 2: 64.6, 3: 61.2, 4: 61.0, 8: 35.7 M sims/s
     if (TAFL_MCTS_TUNE_PARTS_OF(p->flags)) { parts = TAFL_MCTS_TUNE_PARTS_OF(p->flags); if (parts > TAFL_MCTS_MAX_PARTS) parts = TAFL_MCTS_MAX_PARTS; }
     if (parts > grid_of(n)) parts = grid_of(n);
     if (c->n_part_streams == 0) { c->part_stream[0] = c->stream; c->n_part_streams = 1; }
