@@ -349,9 +349,11 @@ def test_mcts_matches_reference_mcts_py_golden(case):
 
 
 @pytest.mark.parametrize("name,G,sims,cpuct,cap", [("copenhagen11", 64, 64, 1.0, 512), ("brandubh7", 128, 200, 1.0, 256),
-                                                  ("tablut9", 64, 96, 1.5, 300), ("copenhagen13", 32, 32, 1.0, 256)])
+                                                  ("tablut9", 64, 96, 1.5, 300), ("copenhagen13", 32, 32, 1.0, 256),
+                                                  ("copenhagen13", 6, 190, 1.0, 48), ("copenhagen11", 6, 400, 1.0, 48)])
 def test_mcts_vs_oracle(name, G, sims, cpuct, cap):
-    """BASELINE config 3 parity: a fixed subset of games reproduced by the CPU oracle bit for bit."""
+    """BASELINE config 3 parity: a fixed subset of games reproduced by the CPU oracle bit for bit.  (The two long searches: a root that
+    grows past the 128 edges whose Qsa signs the tree step caches - 13x13 has 152 legal plays at the start - and deep trees.)"""
     rules, fen, wb, n, lg = _mk(name)
     states = pu.start_states(orc, fen, rules.starting_side, wb, G)
     if name != "copenhagen11":

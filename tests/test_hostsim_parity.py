@@ -140,6 +140,33 @@ def test_mcts(name, sims, cpuct):
     assert list(ostats.reason_hist) == list(hstats.reason_hist)
 
 
+@pytest.mark.parametrize("name,sims,k,target", [("copenhagen13", 190, 8, 4), ("copenhagen13", 170, 4, 0), ("copenhagen11", 300, 8, 4), ("brandubh7", 500, 8, 2)])
+def test_mcts_wide_roots_and_deep_trees(name, sims, k, target):
+    """The tree step keeps the root header and the sign bits of the first 128 root edges in registers (tafl_ops.hpp RootCache): searches
+    whose root grows past 128 children (13x13: 152 legal plays at the start), that visit every root child and go on into deep trees, and
+    that run long enough for every edge array to move several times - against the oracle, bit for bit."""
+    from tests.hostsim import hostsim
+    rules, fen, wb, n, lg, hs = _mk(name)
+    G = 3
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    hostsim.set_spec_k(k, target, 0)
+    try:
+        p = TaflMctsParams(sims, 48, 1.0, 7, 0, 0)
+        ok, on, ostats = orc.batch_mcts(lg, states, G, wb, p, 0)
+        hk, hn, hstats = hs.mcts(states, G, p, 0)
+    finally:
+        hostsim.set_spec_k(4, 0, 0)
+    assert list(on) == list(hn)
+    if name == "copenhagen13":
+        assert max(on) > 128
+    for g in range(G):
+        for j in range(on[g]):
+            a, b = ok[g * 256 + j], hk[g * 256 + j]
+            assert (a.action, a.visits, float(a.q).hex()) == (b.action, b.visits, float(b.q).hex()), (name, g, j)
+    for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+        assert getattr(ostats, f) == getattr(hstats, f), f
+
+
 @pytest.mark.parametrize("k,cooldown", [(1, 0), (2, 0), (2, 1), (3, 2), (4, 0), (4, 4), (8, 0), (8, 3), (8, 8)])
 def test_mcts_speculative_slots_do_not_change_results(k, cooldown):
     """The MCTS pipeline with k playout slots per game (k-1 predicted simulations, `cooldown` = slots per round the search is planned
