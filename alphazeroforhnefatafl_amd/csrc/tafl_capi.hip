@@ -1057,15 +1057,15 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     }
     // every round runs min(capacity, requested) playouts, slot 0 of every waiting game first: progress is guaranteed, and the loop ends
     // as soon as the counters say so
-    const unsigned long long rounds_bound = ((unsigned long long)p->n_sims + 2) * (1 + (unsigned long long)n / (capacity ? capacity : 1));
+    // first read-back of a short search: a large batch always has stragglers that need a few rounds more than the plan (65 536 games: 5 - 6),
+    // and a read-back drains both streams (~0.1 ms) while launches for a finished batch return at once
+    const uint32_t tail_guess = n >= 32768u ? 3u : n >= 4096u ? 2u : n >= 512u ? 1u : 0u;
+    const unsigned long long rounds_bound = ((unsigned long long)p->n_sims + 2 + tail_guess) * (1 + (unsigned long long)n / (capacity ? capacity : 1));
     const uint32_t max_rounds = rounds_bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rounds_bound;
     // Long searches are also read back every 16 rounds before the plan is through: the share of predictions that came true since the last
     // read-back sets how many predicted simulations a game may run beside the pending one (a prediction costs a child expansion in the
     // tree phase whether or not it is consumed: S = 1000 with 44 % hits runs 41.9 M sims/s with one prediction per game, 35.3 M with up to 7).
     const uint32_t probe_every = planned >= 64 ? 16u : 0u;
-    // first read-back of a short search: a large batch always has stragglers that need a few rounds more than the plan (65 536 games: 5 - 6),
-    // and a read-back drains both streams (~0.1 ms) while launches for a finished batch return at once
-    const uint32_t tail_guess = n >= 32768u ? 3u : n >= 4096u ? 2u : n >= 512u ? 1u : 0u;
     uint32_t next_check = probe_every ? probe_every : planned + 1 + tail_guess, wcap = M.spec_k - 1;
     unsigned long long last_hits = 0, last_issued = 0, done_games = 0;
     HIPCHK(hipMemsetAsync(b->trace.p, 0, 8 * TAFL_MCTS_TRACE_ROUNDS, c->stream));
