@@ -50,7 +50,7 @@ template <int NL> struct StateIO {
 };
 
 // ---- MCTS arena -------------------------------------------------------------------------------------------
-struct NodeHdr {                 // 32 bytes
+struct alignas(16) NodeHdr {     // 32 bytes (two 16-byte accesses)
     uint32_t parent;             // node id of the parent (0 for the root)
     uint32_t edge_base;          // first edge of this node inside the game's edge arena
     uint32_t ns;                 // Ns[s]                                   mcts.py:22
@@ -66,12 +66,12 @@ struct NodeHdr {                 // 32 bytes
     uint8_t  expanded;           // s in Ps                                   mcts.py:83
     uint8_t  _pad[2];
 };
-struct Edge { double q; uint32_t n; uint32_t child; };   // Qsa, Nsa (mcts.py:20-21), next state     16 bytes
+struct alignas(16) Edge { double q; uint32_t n; uint32_t child; };   // Qsa, Nsa (mcts.py:20-21), next state     16 bytes
 
 // undo records of the speculation pass (mcts_speculate): the tree is modified in place by ASSUMED playout values to predict the next
 // selections and then restored bit for bit
-struct UndoE { uint32_t idx; uint32_t _pad; Edge e; };     // 24 bytes: edge index inside the game's arena + its old contents
-struct UndoH { uint32_t node; NodeHdr h; };                // 36 bytes
+struct UndoE { uint32_t idx; uint32_t _pad[3]; Edge e; };  // 32 bytes: edge index inside the game's arena + its old contents
+struct UndoH { uint32_t node; uint32_t _pad[3]; NodeHdr h; };   // 48 bytes
 
 struct MctsMem {
     Quad* node_state;            // [(k * G + g) * QUADS]
@@ -374,25 +374,19 @@ struct Ops {
     static TAFL_HD NodeHdr hdr_get(const MctsMem& M, uint32_t g, uint32_t node, const StepCtx& X) {
         uint32_t w[8];
         TAFL_UNROLL for (int i = 0; i < 8; ++i) w[i] = X.rc.hw[i];
-        if (node != 0) {
-            const Quad* p = (const Quad*)&M.hdr[(size_t)node * M.G + g];
-            const Quad a = p[0], b = p[1];
-            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-        }
+        if (node != 0) { const NodeHdr t = M.hdr[(size_t)node * M.G + g]; __builtin_memcpy(w, &t, sizeof t); }
         NodeHdr h; __builtin_memcpy(&h, w, sizeof h);
         return h;
     }
     static TAFL_HD void hdr_put(const MctsMem& M, uint32_t g, uint32_t node, const NodeHdr& h, StepCtx& X) {
         uint32_t w[8]; __builtin_memcpy(w, &h, sizeof h);
-        Quad* p = (Quad*)&M.hdr[(size_t)node * M.G + g];
-        Quad a, b; a.x = w[0]; a.y = w[1]; a.z = w[2]; a.w = w[3]; b.x = w[4]; b.y = w[5]; b.z = w[6]; b.w = w[7];
-        p[0] = a; p[1] = b;
+        M.hdr[(size_t)node * M.G + g] = h;
         TAFL_UNROLL for (int i = 0; i < 8; ++i) X.rc.hw[i] = node == 0 ? w[i] : X.rc.hw[i];
     }
     static TAFL_HD void root_load(const MctsMem& M, uint32_t g, StepCtx& X) {
-        const Quad* p = (const Quad*)&M.hdr[g];
-        const Quad a = p[0], b = p[1];
-        X.rc.hw[0] = a.x; X.rc.hw[1] = a.y; X.rc.hw[2] = a.z; X.rc.hw[3] = a.w; X.rc.hw[4] = b.x; X.rc.hw[5] = b.y; X.rc.hw[6] = b.z; X.rc.hw[7] = b.w;
+        const NodeHdr t = M.hdr[g];
+        uint32_t w[8]; __builtin_memcpy(w, &t, sizeof t);
+        TAFL_UNROLL for (int i = 0; i < 8; ++i) X.rc.hw[i] = w[i];
     }
     // edge `slot` of node `node` now has Qsa q
     static TAFL_HD void pos_note(StepCtx& X, uint32_t node, uint32_t slot, double q) {
@@ -589,12 +583,12 @@ struct Ops {
     };
     static TAFL_HD void log_edge(SpecLog& L, uint32_t eidx, const Edge& old) {
         if (L.ne >= L.cap) { L.ok = false; return; }
-        UndoE u; u.idx = eidx; u._pad = 0; u.e = old;
+        UndoE u; u.idx = eidx; u._pad[0] = u._pad[1] = u._pad[2] = 0; u.e = old;
         L.e[L.ne++] = u;
     }
     static TAFL_HD void log_hdr(SpecLog& L, uint32_t node, const NodeHdr& old) {
         if (L.nh >= L.cap) { L.ok = false; return; }
-        UndoH u; u.node = node; u.h = old;
+        UndoH u; u.node = node; u._pad[0] = u._pad[1] = u._pad[2] = 0; u.h = old;
         L.h[L.nh++] = u;
     }
     // assumed backup: edge `eidx` of node `cur` receives v, then the path to the root as in mcts_backup; every touched record is logged.
