@@ -1059,7 +1059,7 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     // as soon as the counters say so
     // first read-back of a short search: a large batch always has stragglers that need a few rounds more than the plan (65 536 games: 5 - 6),
     // and a read-back drains both streams (~0.1 ms) while launches for a finished batch return at once
-    const uint32_t tail_guess = n >= 32768u ? 3u : n >= 4096u ? 2u : n >= 512u ? 1u : 0u;
+    const uint32_t tail_guess = n >= 32768u ? 5u : n >= 4096u ? 3u : n >= 512u ? 1u : 0u;
     const unsigned long long rounds_bound = ((unsigned long long)p->n_sims + 2 + tail_guess) * (1 + (unsigned long long)n / (capacity ? capacity : 1));
     const uint32_t max_rounds = rounds_bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rounds_bound;
     // Long searches are also read back every 16 rounds before the plan is through: the share of predictions that came true since the last
