@@ -10,7 +10,7 @@ from .abi import (TaflEffects, TaflGmctsStats, TaflMctsParams, TaflMctsStats, Ta
                   TaflState)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("TAFLHIP_LIB") or os.path.join(_HERE, "libtaflhip.so")   # override: timing experiments only
+LIB_PATH = os.path.join(_HERE, "libtaflhip.so")      # the in-tree build; measurement scripts that A/B another build assign LIB_PATH before lib()
 _LIB = None
 
 # every symbol include/taflhip.h declares: (name, restype, argtypes)
@@ -96,12 +96,11 @@ def lib():
                               f"(make -C alphazeroforhnefatafl_amd/csrc). There is no CPU fallback.")
         # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64, and if this library pulled
         # in /opt/rocm's copies first a later `import torch` would find no GPU.  Loading torch first (when it is installed)
-        # makes both share torch's runtime; TAFLHIP_NO_TORCH_PRELOAD=1 skips this for torch-free processes.
-        if not os.environ.get("TAFLHIP_NO_TORCH_PRELOAD"):
-            try:
-                import torch  # noqa: F401
-            except Exception:
-                pass
+        # makes both share torch's runtime.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             f = getattr(L, name)          # AttributeError if the symbol is not exported

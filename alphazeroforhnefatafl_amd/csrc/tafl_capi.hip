@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_encode_boards(Consts<NL> C, const Quad*
 //   temp > 0 : counts ** (1 / temp) (float64 pow of the device math library; exactly the count for temp == 1), summed in ascending action
 //              order like Python's sum(), then divided (mcts.py:50-52).
 //   temp == 0: one-hot on one of the maxima (mcts.py:44-48).  The reference draws it with the process-global np.random.choice; here it is
-//              the first maximum (tie_seed == 0) or the (r mod ties)-th one in ascending action order with r = the taflmix32 word keyed by
+//              the first maximum (tie_seed == 0) or the floor(r * ties / 2^32)-th one in ascending action order with r = the taflmix32 word keyed by
 //              (tie_seed, global game id): reproducible and independent of the sharding.
 __device__ __forceinline__ uint32_t tie_pick(uint64_t tie_seed, uint64_t game_id, uint32_t ties) {
     const uint64_t gk = Engine<2, 7>::game_key(tie_seed, game_id);
@@ -472,7 +472,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 int tafl_fail_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(TAFL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
 
-enum { KC_MOVEGEN = 0, KC_STEP, KC_ROLLOUT, KC_MCTS_TREE, KC_MCTS_ROLLOUT, KC_MCTS_BACKUP, KC_COUNT };
+enum { KC_MOVEGEN = 0, KC_STEP, KC_ROLLOUT, KC_MCTS_TREE, KC_MCTS_ROLLOUT, KC_COUNT };
 
 struct TimedSpan { hipEvent_t a, b; int cls; };
 

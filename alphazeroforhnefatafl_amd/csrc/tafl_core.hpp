@@ -587,8 +587,10 @@ struct Engine {
     struct Outcome { bool over; uint32_t status, reason, winner; };
 
     // `m` must be a valid play of the side to move (destination empty).
-    static TAFL_HD void apply_pre(S& st, const Move& m, const K& C, ApplyCtx& ax) {
-        const uint32_t mover = st.flags & TAFL_F_SIDE;
+    static TAFL_HD void apply_pre(S& st, const Move& m, const K& C, ApplyCtx& ax) { apply_pre(st, m, C, ax, st.flags & TAFL_F_SIDE); }
+    // the same with the mover handed in: `mover` must equal st.flags & TAFL_F_SIDE.  The playout loop of tafl_fast.hpp passes a
+    // compile-time constant (its two half-iterations each serve one side), which folds every `mover ? a : b` below and in captures().
+    static TAFL_HD void apply_pre(S& st, const Move& m, const K& C, ApplyCtx& ax, const uint32_t mover) {
         const B fbit = bit_at<NL>(m.from), tbit = bit_at<NL>(m.to);
         const bool mover_is_king = mover && m.from == king_sq(st, C);
         // board.move_piece (board/state.rs:218-223): clear `from`, set `to` on the mover's side — branch-free
@@ -609,8 +611,9 @@ struct Engine {
 #endif
         if (ax.ncap == 0) st.psc += 1;
     }
-    // skip_enclosure: the caller has PROVED that the enclosure win cannot apply (see tafl_fast.hpp); never set otherwise.
-    static TAFL_HD Outcome outcome_early(const S& st, const ApplyCtx& ax, const K& C, bool skip_enclosure) {
+    // skip_enclosure / skip_fort: the caller has PROVED that the enclosure win / the exit fort cannot apply (see tafl_fast.hpp); never
+    // set otherwise.
+    static TAFL_HD Outcome outcome_early(const S& st, const ApplyCtx& ax, const K& C, bool skip_enclosure, bool skip_fort = false) {
         Outcome o; o.over = false; o.status = TAFL_STATUS_ONGOING; o.reason = 0; o.winner = 0;
         const uint32_t mover = ax.mover;
         const B other = (mover ? st.att : st.def) & C.board;
@@ -639,7 +642,7 @@ struct Engine {
                 o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_KING_ESCAPED; o.winner = 1; o.over = true;
             }
 #ifndef TAFL_ABLATE_FORT
-            else if (C.rules.exit_fort) {
+            else if (C.rules.exit_fort && !skip_fort) {
                 TAFL_PROF_BEGIN(9);
                 const bool fort = exit_fort(st, C);
                 TAFL_PROF_END(9);

@@ -130,7 +130,8 @@ struct Fast {
         g.r[3] = reach1(rev(occN), rev(mineN), rev(kN), fc.vbr, fc.emr, lfsr, fc.lfkr, any_king_lane);
         g.total = 0;
         TAFL_UNROLL for (int d = 0; d < 4; ++d) { g.cnt[d] = popc(g.r[d]); g.total += g.cnt[d]; }
-        g.edge_hit = any(((g.r[0] | g.r[2]) & fc.edge) | ((g.r[1] | g.r[3]) & fc.edger));
+        // (only the enclosure filter reads it: behind an attacker's play, i.e. for a defender's move set)
+        g.edge_hit = side != 0 && any(((g.r[0] | g.r[2]) & fc.edge) | ((g.r[1] | g.r[3]) & fc.edger));
     }
 
     // idx-th play in ROLLOUT ORDER
@@ -160,6 +161,90 @@ struct Fast {
         while (any(r)) { const uint32_t i = lsb(r); r = andn(r, bit_at<NL>(i)); t |= bit_at<NL>(n_to_t(i)); }
     }
 
+    // ---- exit-fort candidate test (exact pre-filter of Engine::exit_fort, logic.rs:572-601) ---------------------------------------------
+    // detect_exit_fort floods {king tile} U {empty tiles} from the king's tile, which must lie on an edge, and gives up (None) as soon as
+    // the region touches an attacker (row_col_enclosed, logic.rs:288-291) or holds a corner (abort_on_corner, :344-346,:368-370).  The
+    // tiles of the king's EDGE LINE next to him belong to that region as long as they are empty (4-connected), so walking from the king
+    // along the edge in either direction the flood meets, first of all, either
+    //   - an attacker                          -> None,
+    //   - the end of the line = a corner tile that is empty (the walk only passes empty tiles) -> None, or
+    //   - a defender                           -> a boundary piece: the only case in which a fort is still possible.
+    // Hence: "on BOTH sides of the king the nearest occupied tile of his edge line exists and is a defender" is necessary for a fort
+    // (a king on a corner has an empty side: no fort, as in Engine::exit_fort where the start tile is a corner).  In random play the test
+    // holds for one defender ply in ~10^3 (tools/playout_event_stats.py), so that the rings and the flood of Engine::exit_fort - paid by
+    // every wave on every defender ply before - are entered by a wave only now and then.  The line is read from the layout in which it is
+    // contiguous: rows 0 / n-1 from N, columns 0 / n-1 from T (= rows 0 / n-1 of T).
+    static TAFL_HD uint32_t line_bits(const B& a, uint32_t base, uint32_t n) {         // n <= 15 bits of `a` from bit `base`
+        return (uint32_t)field64<0>(a, base) & ((1u << n) - 1u);
+    }
+    static TAFL_HD bool fort_candidate(const S& st, const B& attT, const B& defT, const K& C) {
+        const uint32_t kr = TAFL_F_KROW(st.flags), kc = TAFL_F_KCOL(st.flags), n = C.n, last = n - 1u, lb = mul24(last, (uint32_t)W);
+        const bool top = kr == 0u, bot = kr == last, lef = kc == 0u, rig = kc == last;
+        const bool rowline = top || bot;
+        // the four edge lines at fixed positions (literals for a preset), then 2 x 3 selects of n-bit values instead of selects of whole words
+        const uint32_t a0 = line_bits(st.att, 0u, n), a1 = line_bits(st.att, lb, n), a2 = line_bits(attT, 0u, n), a3 = line_bits(attT, lb, n);
+        const uint32_t d0 = line_bits(st.def, 0u, n), d1 = line_bits(st.def, lb, n), d2 = line_bits(defT, 0u, n), d3 = line_bits(defT, lb, n);
+        const uint32_t la = top ? a0 : bot ? a1 : lef ? a2 : a3, ld = top ? d0 : bot ? d1 : lef ? d2 : d3;
+        const uint32_t pos = rowline ? kc : kr;                                       // the king's place on his line (< n <= 15)
+        const uint32_t occ = la | ld;
+        const uint32_t above = occ >> (pos + 1u), below = occ & ((1u << pos) - 1u);
+        const uint32_t first_above = above & (0u - above);                           // nearest occupied tile on the high side
+        const bool ok_hi = (first_above & (ld >> (pos + 1u))) != 0u;                 // ... exists and is a defender
+        const uint32_t hb = 31u - (uint32_t)__builtin_clz(below | 1u);                // nearest occupied tile on the low side (below != 0)
+        const bool ok_lo = below != 0u && ((ld >> hb) & 1u) != 0u;
+        return (top || bot || lef || rig) && kr < n && kc < n && ok_hi && ok_lo;
+    }
+
+    // ---- one ply of a playout with the mover known at compile time -----------------------------------------------------------------------
+    // Every ply flips the side to move, so the playout loop below runs as pairs of half-iterations, the first for an attacker's play, the
+    // second for a defender's: inside a half MOVER is a literal, and every `mover ? a : b` of apply_pre / captures / track / gen /
+    // outcome_early folds away - with it the code of the other side: the king's own rays and the enclosure test exist only behind an
+    // attacker's play, the king-escape and exit-fort tests only behind a defender's, the king-capture block only in the attacker's half.
+    // 64 games share an instruction stream: before, a wave paid for both sides' code on every ply.
+    // g: plays of MOVER on entry, of the other side on exit; rk: the ply's RNG word before mixing (sk + ply * 0x85EBCA77, kept incrementally).
+    template <uint32_t MOVER>
+    static TAFL_HD void ply_of(S& st, B& attT, B& defT, Gen& g, uint32_t& rk, const K& C, const F& fc) {
+        TAFL_PROF_COUNT(31); TAFL_STAT_HIT(31);
+        TAFL_PROF_BEGIN(10); TAFL_PROF_SPLIT(10); TAFL_PROF_END(11);      // two empty sections: the cost of a mark
+        TAFL_PROF_BEGIN(0);
+        const uint32_t idx = E::mulhi(E::fmix32(rk), g.total);
+        rk += 0x85EBCA77u;
+        const Move m = pick(st, attT, defT, g, idx, C);
+        TAFL_PROF_SPLIT(0);
+        typename E::ApplyCtx ax;
+        E::apply_pre(st, m, C, ax, MOVER);
+        TAFL_PROF_SPLIT(4);
+        // T layout upkeep: the move, the custodial captures (V+- are +-1 here, H+- are +-W), then whatever else was
+        // captured (shieldwall, king, Linnaean: rare)
+        {
+            constexpr int BK = 2 * W;
+            const uint32_t tT = n_to_t(m.to);
+            const B mvT = bit_at<NL>(n_to_t(m.from)) | bit_at<NL>(tT);
+            if constexpr (MOVER != 0) defT = defT ^ mvT; else attT = attT ^ mvT;
+            const uint32_t cu = ax.cust;
+            const uint64_t cf = ((uint64_t)(cu & 1u) << (BK + 1)) | ((uint64_t)((cu >> 1) & 1u) << (BK - 1))
+                              | ((uint64_t)((cu >> 2) & 1u) << (BK + W)) | ((uint64_t)((cu >> 3) & 1u) << (BK - W));
+            const B cT = deposit64<BK, NL>(cf, tT);
+            if constexpr (MOVER != 0) attT = andn(attT, cT); else defT = andn(defT, cT);       // custodial victims are the other side's
+            if (ax.ncap != 0) TAFL_STAT_HIT(11);
+            if (ax.ncap != (uint32_t)__builtin_popcount(cu)) {
+                TAFL_STAT_HIT(12);
+                B c = ax.caps;
+                while (any(c)) { const uint32_t i = lsb(c); c = andn(c, bit_at<NL>(i)); const B cb = bit_at<NL>(n_to_t(i)); attT = andn(attT, cb); defT = andn(defT, cb); }
+            }
+        }
+        // opponent's plays on the post-move board: no-plays test, enclosure filter, and the next ply's move set
+        TAFL_PROF_SPLIT(5);
+        gen(st, attT, defT, MOVER ^ 1u, C, fc, g);
+        TAFL_PROF_SPLIT(6);
+        bool skip_encl = false, skip_fort = false;
+        if constexpr (MOVER == 0) skip_encl = C.rules.enclosure_win == TAFL_ENCL_WITHOUT_EDGE_ACCESS && (g.edge_hit || any(st.def & C.edge));
+        else if (C.rules.exit_fort) { skip_fort = !fort_candidate(st, attT, defT, C); if (!skip_fort) TAFL_STAT_HIT(13); }
+        const typename E::Outcome o = E::outcome_early(st, ax, C, skip_encl, skip_fort);
+        E::apply_finish(st, ax, o, o.over ? 1u : g.total, C);
+        TAFL_PROF_END(7);
+    }
+
     // one seeded uniform-random playout; identical results to Engine::rollout
     static TAFL_HD void rollout(S& st, uint32_t sk, uint32_t max_plies, const K& C, tafl_rollout_result& res) {
         const F fc = make_fast_consts<NL>(C);
@@ -169,47 +254,19 @@ struct Fast {
         Gen g;
         if (TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) gen(st, attT, defT, start_side, C, fc, g);
         else { TAFL_UNROLL for (int d = 0; d < 4; ++d) { g.r[d] = bz<NL>(); g.cnt[d] = 0; } g.total = 0; g.edge_hit = false; }
-        uint32_t ply = 0; bool stuck = false;
-        while (ply < max_plies && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
-            if (g.total == 0) { stuck = true; break; }
-            TAFL_PROF_COUNT(31); TAFL_STAT_HIT(31);
-            TAFL_PROF_BEGIN(10); TAFL_PROF_SPLIT(10); TAFL_PROF_END(11);      // two empty sections: the cost of a mark
-            TAFL_PROF_BEGIN(0);
-            const uint32_t idx = E::mulhi(E::ply_rand(sk, ply), g.total);
-            const Move m = pick(st, attT, defT, g, idx, C);
-            TAFL_PROF_SPLIT(0);
-            typename E::ApplyCtx ax;
-            E::apply_pre(st, m, C, ax);
-            TAFL_PROF_SPLIT(4);
-            // T layout upkeep: the move, the custodial captures (V+- are +-1 here, H+- are +-W), then whatever else was
-            // captured (shieldwall, king, Linnaean: rare)
-            {
-                constexpr int BK = 2 * W;
-                const uint32_t tT = n_to_t(m.to);
-                const B mvT = bit_at<NL>(n_to_t(m.from)) | bit_at<NL>(tT);
-                defT = defT ^ gate(mvT, ax.mover != 0); attT = attT ^ gate(mvT, ax.mover == 0);
-                const uint32_t cu = ax.cust;
-                const uint64_t cf = ((uint64_t)(cu & 1u) << (BK + 1)) | ((uint64_t)((cu >> 1) & 1u) << (BK - 1))
-                                  | ((uint64_t)((cu >> 2) & 1u) << (BK + W)) | ((uint64_t)((cu >> 3) & 1u) << (BK - W));
-                const B cT = deposit64<BK, NL>(cf, tT);
-                attT = andn(attT, cT); defT = andn(defT, cT);
-                if (ax.ncap != 0) TAFL_STAT_HIT(11);
-                if (ax.ncap != (uint32_t)__builtin_popcount(cu)) {
-                    TAFL_STAT_HIT(12);
-                    B c = ax.caps;
-                    while (any(c)) { const uint32_t i = lsb(c); c = andn(c, bit_at<NL>(i)); const B cb = bit_at<NL>(n_to_t(i)); attT = andn(attT, cb); defT = andn(defT, cb); }
-                }
-            }
-            // opponent's plays on the post-move board: no-plays test, enclosure filter, and the next ply's move set
-            TAFL_PROF_SPLIT(5);
-            gen(st, attT, defT, ax.mover ^ 1u, C, fc, g);
-            TAFL_PROF_SPLIT(6);
-            const bool skip_encl = ax.mover == 0 && C.rules.enclosure_win == TAFL_ENCL_WITHOUT_EDGE_ACCESS
-                                   && (g.edge_hit || any(st.def & C.edge));
-            const typename E::Outcome o = E::outcome_early(st, ax, C, skip_encl);
-            E::apply_finish(st, ax, o, o.over ? 1u : g.total, C);
-            ++ply;
-            TAFL_PROF_END(7);
+        uint32_t ply = 0, rk = sk; bool stuck = false;
+        // a playout goes on while the game is on, the cap is not reached and the side to move has a play (else: stuck)
+        auto goes_on = [&]() -> bool {
+            if (!(ply < max_plies && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING)) return false;
+            if (g.total == 0) { stuck = true; return false; }
+            return true;
+        };
+        bool active = goes_on();
+        bool skip_first = start_side != 0;     // a playout that starts with a defender's play sits out the first (attacker's) half
+        while (wave_any(active)) {
+            if (active && !skip_first) { ply_of<0>(st, attT, defT, g, rk, C, fc); ++ply; active = goes_on(); }
+            skip_first = false;
+            if (active) { ply_of<1>(st, attT, defT, g, rk, C, fc); ++ply; active = goes_on(); }
         }
         E::finish_rollout(st, start_side, ply, stuck, res);
     }

@@ -440,9 +440,10 @@ struct Ops {
         const double sq = sqrt((double)h.ns);
         double cur_best = -__builtin_inf(); int best = -1;
         const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
-        if (h.m < h.n_legal && c_puct >= 0.0) {
+        if (h.m < h.n_legal && c_puct > 0.0) {
             // While an unvisited action exists it scores u0 = cp * sqrt(Ns + EPS) > cp * sqrt(Ns) / 2 >= cp * sqrt(Ns) / (1 + Nsa) for every
-            // visited one (Nsa >= 1), so a visited action with Qsa <= 0 can neither win nor tie: only the (few) actions with Qsa > 0 are
+            // visited one (Nsa >= 1; strict only for cp > 0: at c_puct == 0 a visited action with Qsa == 0 ties u0 = 0 and, having the lower
+            // index, wins - that case takes the full scan below), so a visited action with Qsa <= 0 can neither win nor tie: only the (few) actions with Qsa > 0 are
             // evaluated, in ascending order as mcts.py does - the float64 division is the expensive part of this loop and 64 games share
             // an instruction stream (-24 % VALU instructions in k_mcts_tree).  Same argmax, same tie rule.
             // At the root the sign bits come from the step's cache (scanned once per step, kept current by every backup).
@@ -801,16 +802,8 @@ struct Ops {
                 uint8_t sk[kMctsMaxSlots];
                 TAFL_UNROLL for (uint32_t t = 1; t < kMctsMaxSlots; ++t) sk[t] = M.spec_kind[(size_t)(t < had ? t : 0u) * M.G + g];      // independent loads
                 TAFL_UNROLL for (uint32_t t = 1; t < kMctsMaxSlots; ++t) issued += (t < had && (sk[t] == 1 || sk[t] == 2)) ? 1u : 0u;
-#ifndef TAFL_SPEC_POLICY
-#define TAFL_SPEC_POLICY 1
-#endif
-#if TAFL_SPEC_POLICY == 0
-                w = (hits >= issued) ? w + 1u : hits + 1u;
-#elif TAFL_SPEC_POLICY == 1
+                // a fully consumed issue widens by one; after a miss the width falls half-way back to what came true (+1)
                 w = (hits >= issued) ? w + 1u : ((w + hits + 1u) / 2u > hits + 1u ? (w + hits + 1u) / 2u : hits + 1u);
-#else
-                w = (hits >= issued) ? w + 1u : (hits > 0 ? (w > hits + 1u ? w : hits + 1u) : (w + 1u) / 2u);
-#endif
             }
             if (w > M.spec_k - 1) w = M.spec_k - 1;
             M.spec_w[g] = (uint8_t)w;

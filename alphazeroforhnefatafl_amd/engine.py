@@ -15,7 +15,7 @@ from . import abi
 from ._lib import check, lib
 from .abi import (TaflEffects, TaflGmctsStats, TaflMctsParams, TaflMctsStats, TaflPlay, TaflRolloutResult, TaflRootChild, TaflState)
 
-KC_MOVEGEN, KC_STEP, KC_ROLLOUT, KC_MCTS_TREE, KC_MCTS_ROLLOUT, KC_MCTS_BACKUP = range(6)
+KC_MOVEGEN, KC_STEP, KC_ROLLOUT, KC_MCTS_TREE, KC_MCTS_ROLLOUT = range(5)
 
 
 class BatchedGameLogic:
@@ -28,7 +28,7 @@ class BatchedGameLogic:
         self.word_bits = word_bits or abi.word_bits_for(side_len)
         self.device = device
         self._c_rules = rules.to_c()
-        self._batches = []               # weak references to the GameBatch objects created on this context
+        self._batches = weakref.WeakSet()   # the open GameBatch objects of this context (a batch leaves the set when it is closed or collected)
         self._h = C.c_void_p()
         check(lib().tafl_ctx_create(C.byref(self._c_rules), side_len, self.word_bits, device,
                                     C.c_void_p(stream) if stream else None, C.byref(self._h)))
@@ -37,10 +37,8 @@ class BatchedGameLogic:
         """Destroys the context; batches created from it that are still open are closed first (the library refuses to destroy a
         context with live batches)."""
         if self._h:
-            for ref in list(self._batches):
-                b = ref()
-                if b is not None:
-                    b.close()
+            for b in list(self._batches):
+                b.close()
             self._batches.clear()
             check(lib().tafl_ctx_destroy(self._h))
             self._h = C.c_void_p()
@@ -95,12 +93,13 @@ class GameBatch:
         self.n = n_games
         self._h = C.c_void_p()
         check(lib().tafl_batch_create(logic._h, n_games, C.byref(self._h)))
-        logic._batches.append(weakref.ref(self))
+        logic._batches.add(self)
 
     def close(self):
         if self._h:
             lib().tafl_batch_destroy(self._h)
             self._h = C.c_void_p()
+            self.logic._batches.discard(self)
 
     def __del__(self):
         try:

@@ -193,7 +193,7 @@ def mcts_bytes_per_sim(stats, side):
 
 def timed_mcts(logic, batch, sims, cpuct, seed, cap, base, steps, warmup, sync, flags=0):
     """W warm-up + K timed mcts_run steps on an existing batch; returns (elapsed_s, stats, kernel-class timings)."""
-    from alphazeroforhnefatafl_amd.engine import KC_MCTS_BACKUP, KC_MCTS_ROLLOUT, KC_MCTS_TREE
+    from alphazeroforhnefatafl_amd.engine import KC_MCTS_ROLLOUT, KC_MCTS_TREE
     for _ in range(warmup):
         batch.mcts_run(sims, cpuct, seed, cap, game_id_base=base, flags=flags)
     sync()
@@ -205,7 +205,7 @@ def timed_mcts(logic, batch, sims, cpuct, seed, cap, base, steps, warmup, sync, 
     sync()
     elapsed = time.perf_counter() - t0
     logic.timing_enable(False)
-    kt = {"rollout": logic.timing_get(KC_MCTS_ROLLOUT), "tree": logic.timing_get(KC_MCTS_TREE), "backup": logic.timing_get(KC_MCTS_BACKUP)}
+    kt = {"rollout": logic.timing_get(KC_MCTS_ROLLOUT), "tree": logic.timing_get(KC_MCTS_TREE)}
     return elapsed, batch.mcts_stats(), kt
 
 
@@ -435,7 +435,6 @@ def main():
                         "the HBM roof; the binding limit is integer VALU issue (DESIGN.md section 6: per-class issue costs in profiles/r01_valu_rates, "
                         "opcode-class histogram in profiles/r02_opclass)")
         tree_ms, tree_n = kt["tree"]
-        bk_ms, bk_n = kt["backup"]
         roll_ms, roll_n = kt["rollout"]
         out = {
             "metric": "mcts_sims_per_sec", "value": total_sims / elapsed, "unit": "sims/s",
@@ -458,8 +457,7 @@ def main():
                      "algorithmic_bytes_per_sim": bps,
                      "hbm_frac_sims": (total_sims / elapsed / world) * bps / (HBM_PEAK_GBS * 1e9)},
             "kernels_ms": {kname: {"avg": roll_ms / max(roll_n, 1), "launches": int(roll_n), "total_per_step": roll_ms / args.steps},
-                           "k_mcts_tree": {"avg": tree_ms / max(tree_n, 1), "launches": int(tree_n), "total_per_step": tree_ms / args.steps},
-                           "k_mcts_tree(final backup)": {"avg": bk_ms / max(bk_n, 1), "launches": int(bk_n)}},
+                           "k_mcts_tree": {"avg": tree_ms / max(tree_n, 1), "launches": int(tree_n), "total_per_step": tree_ms / args.steps}},
             "roofline": roof,
         }
         batch.close()

@@ -343,9 +343,9 @@ int tafl_mcts_play_best(tafl_batch* b, tafl_play* out_plays, tafl_effects* out_e
  * torch tensor's data_ptr): the second form never crosses PCIe. */
 int tafl_encode_boards(tafl_batch* b, uint8_t* out, int out_is_device);
 int tafl_mcts_policy_device(tafl_batch* b, double temp, double* out, int out_is_device);
-/* the same with the choices mcts.py:44-45 leaves to np.random: temp == 0 puts the 1 on the (r mod ties)-th maximum in ascending action
+/* the same with the choices mcts.py:44-45 leaves to np.random: temp == 0 puts the 1 on the floor(r * ties / 2^32)-th maximum in ascending action
  * order, r = taflmix32 word of (tie_seed, game_id_base + game); tie_seed == 0 = the first maximum.  Any temp >= 0: counts ** (1 / temp) is the
- * device math library's float64 pow (exact for temp == 1; within 2 ulp of the host's pow otherwise, tests/test_gpu_parity.py). */
+ * device math library's float64 pow (exact for temp == 1; within 4 ulp of the host's pow otherwise, tests/test_gpu_parity.py). */
 int tafl_mcts_policy_device_ex(tafl_batch* b, double temp, uint64_t tie_seed, uint64_t game_id_base, double* out, int out_is_device);
 
 /* ---- guided MCTS: src/mcts.py:55-136 with the CALLER's network as nnet.predict (mcts.py:85), SURVEY.md section 8f rank 3 ---
@@ -396,7 +396,7 @@ int tafl_replay_read(const char* path, uint8_t side_len, uint32_t max_records, u
 
 /* ---- measurement helpers (bench.py) -----------------------------------------------------------------
  * HIP-event timing on the ctx stream: average duration of the named kernel class since the last reset.
- * classes: 0 movegen, 1 step, 2 rollout, 3 mcts_select_expand, 4 mcts_rollout, 5 mcts_backup */
+ * classes: 0 movegen, 1 step, 2 rollout, 3 mcts tree step (k_mcts_tree), 4 mcts playouts (k_mcts_rollout / k_mcts_fused) */
 int tafl_mcts_round_trace(tafl_batch* b, uint32_t* requested, uint32_t* run, uint32_t cap, uint32_t* n_rounds); /* playouts requested /
     run in each round of the last tafl_mcts_run (two-kernel pipeline; 0 rounds after a fused search); arrays may be NULL */
 int tafl_timing_enable(tafl_ctx* ctx, int enable);

@@ -119,7 +119,10 @@ def test_rollouts(name):
 
 
 @pytest.mark.parametrize("name,sims,cpuct", [("copenhagen11", 48, 1.0), ("brandubh7", 200, 1.0), ("tablut9", 64, 1.5),
-                                             ("copenhagen13", 24, 1.0)])
+                                             ("copenhagen13", 24, 1.0),
+                                             # c_puct == 0: an unvisited action scores 0 and TIES a visited one with Qsa == 0, which then wins
+                                             # by its lower index (mcts.py:117-119): puct_pick's Qsa > 0 shortcut must not be taken
+                                             ("brandubh7", 300, 0.0), ("copenhagen11", 200, 0.0), ("brandubh7", 120, 1e-300)])
 def test_mcts(name, sims, cpuct):
     rules, fen, wb, n, lg, hs = _mk(name)
     G = 24

@@ -26,7 +26,7 @@ L.hs_rollout.argtypes = [C.POINTER(TaflRules), C.c_uint8, C.c_uint32, C.POINTER(
 assert L.hs_rollout(C.byref(r), n, wb, states, G, 2, 0, 512, 0, out) == 0
 N = acc[31]
 names = {0: 'exit_fort entered (defender moved)', 1: 'king on edge', 2: 'ring1: no attacker next to king', 3: 'ring1 empty nb, no corner', 4: 'ring2 passed -> flood', 5: 'flood ok -> secure',
-         8: 'shieldwall filter passed', 9: 'king adjacent', 10: 'enclosure flood entered', 11: 'ply with captures', 12: 'non-custodial captures'}
+         13: 'fort candidate (edge-line flank test)', 8: 'shieldwall filter passed', 9: 'king adjacent', 10: 'enclosure flood entered', 11: 'ply with captures', 12: 'non-custodial captures'}
 print(board, 'plies', N)
 for k, nm in names.items():
     p = acc[k] / N
