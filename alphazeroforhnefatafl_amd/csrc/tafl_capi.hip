@@ -190,6 +190,11 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_random_advance(Consts<NL> Carg, 
 
 // ---- MCTS kernels ---------------------------------------------------------------------------------
 enum { ST_SIMS = 0, ST_ROLLOUTS, ST_PLIES, ST_DEPTH, ST_SCANNED, ST_TERMINAL, ST_FAULTS, ST_SPEC_ISSUED, ST_REASON0 = 8, ST_SPEC_HITS = 24, ST_EXEC = 25, ST_DONE = 26, ST_COUNT = 28 };
+// control words of a search in flight (device memory, one set per batch): the width cap of the prediction pass is steered ON THE DEVICE
+// from the hit rate of the last window, so that a whole search can be enqueued without a single read-back (tafl_mcts_run_async)
+enum { CT_WCAP = 0, CT_LAST_ISSUED, CT_LAST_HITS, CT_NEXT_CHECK, CT_COUNT };
+static_assert(CT_COUNT == 4, "SearchPlan::ctrl0");
+__device__ __forceinline__ unsigned long long ld_counter(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -211,8 +216,8 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_init(Consts<NL> C, const Qu
 // tree phase of the simulation pipeline: consume finished playouts (backup), run as many further simulations as can be
 // served by ready slots, then issue the next slots (tafl_ops.hpp mcts_tree_step)
 template <int NL, int W, int PRESET>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, uint32_t wcap,
-                                                          unsigned long long* stats, uint32_t* work, uint32_t* work_count, const uint32_t* prev_count, uint32_t capacity,
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, uint32_t round, uint32_t planned, uint32_t probe_every,
+                                                          uint32_t target, unsigned long long* stats, const unsigned long long* ctrl, uint32_t* work, uint32_t* work_count,
                                                           uint32_t g_begin, uint32_t g_end) {
     const uint32_t g = g_begin + blockIdx.x * TAFL_BLOCK + threadIdx.x;     // this launch serves games g_begin .. g_end - 1
     // the tree phase of one half of the batch runs beside the other half's playouts (2 - 4 waves per SIMD): it is one latency-bound wave
@@ -223,7 +228,14 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
     ls.reason_hist4 = 0; ls.spec_issued = ls.spec_hits = 0;
     const bool live = g < g_end && (M.sim_next[g] < n_sims || M.kind[g] == 1);
     if (__ballot(live) == 0ull) return;                       // whole wave finished: nothing to do, nothing to count
-    (void)prev_count; (void)capacity;
+    // Plan (wave-uniform): inside the plan a game issues ceil(remaining / rounds left) slots.  Past it: 1 = "use every slot that exists"
+    // (wasted playouts are free on an emptying device) for short searches and, for long ones, once three quarters of the games are done;
+    // until then 0 = every game keeps to what its own hit history allows (a long search whose predictions fail runs far beyond the plan
+    // with every game still alive: S = 1000 runs 44 M sims/s this way, 39 M otherwise).  Both only steer WHEN playouts run, never a result.
+    uint32_t rounds_left;
+    if (round < planned) rounds_left = planned - round;
+    else rounds_left = (probe_every == 0u || 4ull * ld_counter(&stats[ST_DONE]) >= 3ull * (unsigned long long)M.G) ? 1u : 0u;
+    const uint32_t wcap = (uint32_t)ld_counter(&ctrl[CT_WCAP]);
     if (live) Ops<NL, W>::mcts_tree_step(M, g, c_puct, n_sims, rounds_left, target, wcap, C, ls);
     {   // games that completed their last simulation in this launch (a finished game is never live again: counted once)
         const unsigned long long fin = __ballot(live && M.sim_next[g] >= n_sims && M.kind[g] != 1);
@@ -261,7 +273,8 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
 template <int NL, int W, int PRESET>
 __global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_mcts_rollout(Consts<NL> Carg, MctsMem M, uint64_t seed, uint64_t base, uint32_t sim_offset,
                                                                        uint32_t max_plies, const uint32_t* work, const uint32_t* work_count, uint32_t* next_count,
-                                                                       uint32_t stride, uint32_t capacity, unsigned long long* stats, uint32_t* trace) {
+                                                                       uint32_t stride, uint32_t capacity, unsigned long long* stats, uint32_t* trace,
+                                                                       unsigned long long* ctrl, uint32_t round, uint32_t planned, uint32_t probe_every) {
     // entry i of the concatenated per-class work lists; entries beyond `capacity` (what the device holds at once) wait for the next round
     uint32_t pre[TAFL_MCTS_MAX_SLOTS + 1];
     pre[0] = 0;
@@ -270,6 +283,21 @@ __global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_m
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (trace) { trace[0] = pre[TAFL_MCTS_MAX_SLOTS]; trace[1] = cnt; }                // this round: requested, run
         TAFL_UNROLL for (uint32_t t = 0; t < TAFL_MCTS_MAX_SLOTS; ++t) next_count[t] = 0;     // the next round's counters (the other buffer)
+        // Width control of long searches (ctrl is handed to the first partition's launches only): every `probe_every` rounds inside the plan,
+        // every few rounds past it, the share of predictions that came true since the last look sets how many predicted simulations a game
+        // may run beside the pending one (a prediction costs a child expansion in the tree phase and, when it fails, a playout: S = 1000 runs
+        // 50.6 M sims/s with the thresholds below, 45.5 M when the windows with 45 - 75 % hits get three predictions instead of one, S = 256
+        // 63.8 M with them and 62.0 M with narrower ones; measured in round 2 with the same rule on the host).
+        if (ctrl && probe_every && (unsigned long long)round + 1ull >= ctrl[CT_NEXT_CHECK]) {
+            const unsigned long long issued = ld_counter(&stats[ST_SPEC_ISSUED]), hits = ld_counter(&stats[ST_SPEC_HITS]);
+            const unsigned long long di = issued - ctrl[CT_LAST_ISSUED], dh = hits - ctrl[CT_LAST_HITS];
+            ctrl[CT_LAST_ISSUED] = issued; ctrl[CT_LAST_HITS] = hits;
+            unsigned long long wcap = ctrl[CT_WCAP];
+            if (di > (unsigned long long)M.G / 4ull) wcap = 100ull * dh > 85ull * di ? M.spec_k - 1u : 100ull * dh > 75ull * di ? 3u : 100ull * dh > 70ull * di ? 2u : 1u;
+            else if (wcap < M.spec_k - 1u) wcap += 1ull;                  // hardly anything was predicted: probe one wider
+            __hip_atomic_store(&ctrl[CT_WCAP], wcap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctrl[CT_NEXT_CHECK] = (unsigned long long)round + 1ull + (round + 1u < planned ? probe_every : (planned >= 32u ? 4u : 2u));
+        }
     }
     if (blockIdx.x * TAFL_BLOCK >= cnt) return;
     const uint32_t i = blockIdx.x * TAFL_BLOCK + threadIdx.x;
@@ -485,9 +513,6 @@ struct tafl_ctx {
     Consts<2> c2; Consts<4> c4; Consts<8> c8;
     Consts<6> c6;                    // the 13x13 preset in the dense 13-column search layout (preset == PRESET_COPENHAGEN13 only)
     int preset;                      // PRESET_* detected at ctx_create: selects kernels with compile-time constants
-    hipStream_t part_stream[TAFL_MCTS_MAX_PARTS];   // streams of the partitioned MCTS pipeline ([0] = stream; the others are created on first use)
-    hipEvent_t ev_fork[TAFL_MCTS_MAX_PARTS], ev_join[TAFL_MCTS_MAX_PARTS];
-    uint32_t n_part_streams;
     uint32_t live_batches;           // batches created on this context and not yet destroyed (tafl_ctx_destroy refuses while > 0)
     uint32_t rollout_capacity;       // playouts k_mcts_rollout holds on the device at once (occupancy x CUs x 64 lanes); 0 = not asked yet
     bool timing;
@@ -507,9 +532,28 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// a search in flight on a batch: tafl_mcts_run_async enqueues the whole plan, tafl_mcts_wait joins it (and runs the stragglers' rounds)
+struct SearchPart { uint32_t g0, g1, cap, grid_tree, grid_roll; hipStream_t s; uint32_t* wl; uint32_t* wc; };
+struct SearchPlan {
+    bool active, fused;
+    tafl_mcts_params p; uint64_t base;
+    MctsMem M;
+    uint32_t parts, slots, planned, probe_every, next_round, max_rounds;
+    unsigned long long ctrl0[4];     // initial control words (CT_*): source of an asynchronous copy
+    SearchPart P[TAFL_MCTS_MAX_PARTS];
+};
+
 struct tafl_batch {
     tafl_ctx* ctx;
     uint32_t n;
+    // searches run on streams of the BATCH (created on first use), forked from the context's stream when the search is enqueued and joined
+    // by tafl_mcts_wait: two batches of one context search side by side
+    hipStream_t sstream[TAFL_MCTS_MAX_PARTS];
+    hipEvent_t ev_fork[TAFL_MCTS_MAX_PARTS], ev_start, ev_half;
+    uint32_t n_sstreams;
+    bool half_recorded;              // ev_half sits in the stream of the search in flight (half of its planned rounds are enqueued before it)
+    SearchPlan plan;
+    DevBuf ctrl;
     Quad* soa;                       // quad-plane SoA: [QUADS][n]
     DevBuf plays, effects, counts, masks, codes, ranks, results, out_plays, u8out, plies;
     // MCTS
@@ -621,7 +665,7 @@ int tafl_ctx_create(const tafl_rules* rules, uint8_t side_len, uint32_t word_bit
     tafl_ctx* c = new (std::nothrow) tafl_ctx();
     if (!c) return fail(TAFL_ERR_OOM, "out of host memory");
     c->rules = *rules; c->n = side_len; c->word_bits = word_bits; c->nl = (uint32_t)l64 * 2; c->w = (uint32_t)rw; c->device = device;
-    c->timing = false; c->rollout_capacity = 0; c->n_part_streams = 0; c->live_batches = 0;
+    c->timing = false; c->rollout_capacity = 0; c->live_batches = 0;
     c->preset = detect_preset(*rules, side_len, word_bits);
     for (int i = 0; i < KC_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
     int rc = 0;
@@ -641,10 +685,6 @@ int tafl_ctx_destroy(tafl_ctx* c) {
     if (c->live_batches != 0) return fail(TAFL_ERR_INVALID_ARG, "tafl_ctx_destroy: batches of this context are still alive (destroy them first)");
     (void)hipSetDevice(c->device);
     drain_spans(c);
-    for (uint32_t k = 1; k < c->n_part_streams; ++k) {
-        (void)hipStreamSynchronize(c->part_stream[k]); (void)hipStreamDestroy(c->part_stream[k]);
-        (void)hipEventDestroy(c->ev_fork[k]); (void)hipEventDestroy(c->ev_join[k]);
-    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TAFL_OK;
@@ -701,7 +741,8 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     if (!b) return fail(TAFL_ERR_OOM, "out of host memory");
     b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr; b->g_has = false; b->g_max_sims = 0; b->trace_rounds = 0;
     b->spec_k = TAFL_MCTS_MAX_SLOTS;
-    memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats);
+    b->n_sstreams = 0; b->half_recorded = false;
+    memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats); memset(&b->plan, 0, sizeof b->plan);
     const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
     if (hipMalloc((void**)&b->soa, bytes) != hipSuccess) { delete b; return fail(TAFL_ERR_OOM, "hipMalloc(batch states) failed"); }
     if (hipMemsetAsync(b->soa, 0, bytes, c->stream) != hipSuccess) { (void)hipFree(b->soa); delete b; return fail(TAFL_ERR_HIP, "hipMemsetAsync failed"); }
@@ -714,12 +755,16 @@ int tafl_batch_destroy(tafl_batch* b) {
     if (!b) return TAFL_OK;
     if (b->ctx->live_batches > 0) b->ctx->live_batches -= 1;
     (void)hipSetDevice(b->ctx->device);
+    for (uint32_t k = 0; k < b->n_sstreams; ++k) {           // a search in flight is abandoned: let its launches drain, then free
+        (void)hipStreamSynchronize(b->sstream[k]); (void)hipStreamDestroy(b->sstream[k]); (void)hipEventDestroy(b->ev_fork[k]);
+    }
+    if (b->n_sstreams) { (void)hipEventDestroy(b->ev_start); (void)hipEventDestroy(b->ev_half); }
     (void)hipStreamSynchronize(b->ctx->stream);
     if (b->soa) (void)hipFree(b->soa);
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_meta, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->ulog_e, &b->ulog_h, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace,
+                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->ulog_e, &b->ulog_h, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
                       &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
     for (DevBuf* d : bufs) d->release();
@@ -923,6 +968,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * arena_quads(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
     NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_node, k * n * 4); NEED(b->spec_ord, k * n * 4); NEED(b->spec_first, n * 4);
     NEED(b->spec_n, n); NEED(b->spec_w, n); NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
+    NEED(b->ctrl, sizeof(unsigned long long) * CT_COUNT);
     NEED(b->ulog_e, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoE)); NEED(b->ulog_h, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoH));
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
@@ -938,18 +984,97 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     return TAFL_OK;
 }
 
-int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base) {
+// ---- the search driver -------------------------------------------------------------------------------------------------------------
+// tafl_mcts_run_async enqueues a whole search - the planned rounds plus the rounds its stragglers usually need - on the batch's own
+// streams WITHOUT reading anything back: plan and width control live on the device (k_mcts_tree / k_mcts_rollout read the counters
+// themselves), launches for a finished batch return at once.  tafl_mcts_wait joins the streams, reads the counters and, while games are
+// still unfinished, runs further rounds: a search always completes (or the call fails), however many rounds its slowest game needs.
+// tafl_mcts_run = the two back to back.  Results never depend on how a search was enqueued.
+static int search_streams(tafl_batch* b, uint32_t parts) {
+    if (b->n_sstreams == 0) {
+        HIPCHK(hipEventCreateWithFlags(&b->ev_start, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_half, hipEventDisableTiming));
+    }
+    while (b->n_sstreams < parts) {
+        const uint32_t k = b->n_sstreams;
+        HIPCHK(hipStreamCreateWithFlags(&b->sstream[k], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_fork[k], hipEventDisableTiming));
+        b->n_sstreams = k + 1;
+    }
+    return TAFL_OK;
+}
+
+// rounds [next_round, next_round + count) of the two-kernel pipeline: per round and partition one tree launch (one game per lane: backups,
+// real selections, slot matching, prediction of the next slots, dense work lists) and one playout launch over the work lists
+static int mcts_enqueue_rounds(tafl_batch* b, uint32_t count, bool stagger) {
+    tafl_ctx* c = b->ctx; SearchPlan& sp = b->plan; const tafl_mcts_params* p = &sp.p;
+    unsigned long long* st = (unsigned long long*)b->stats.p; unsigned long long* ctrl = (unsigned long long*)b->ctrl.p;
+    const MctsMem& M = sp.M;
+    for (uint32_t r = 0; r < count; ++r) {
+        const uint32_t i = sp.next_round;
+        if (i >= sp.max_rounds) return fail(TAFL_ERR_CAPACITY, "tafl_mcts: the search did not finish within its round bound");
+        b->trace_rounds = i + 1;
+        for (uint32_t k = 0; k < sp.parts; ++k) {
+            const SearchPart& pk = sp.P[k];
+            uint32_t* wc_now = pk.wc + (i & 1u) * TAFL_MCTS_MAX_SLOTS; uint32_t* wc_next = pk.wc + ((i + 1u) & 1u) * TAFL_MCTS_MAX_SLOTS;
+            {
+                SpanGuard sg(c, KC_MCTS_TREE, pk.s);
+                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->c_puct, p->n_sims, i, sp.planned, sp.probe_every,
+                                                      sp.slots, st, ctrl, pk.wl, wc_now, pk.g0, pk.g1));
+            }
+            // partition k+1 starts behind partition k's first tree launch: from then on the tree phases are spread over a round
+            if (stagger && k + 1 < sp.parts) {
+                if (hipEventRecord(b->ev_fork[k + 1], pk.s) != hipSuccess || hipStreamWaitEvent(sp.P[k + 1].s, b->ev_fork[k + 1], 0) != hipSuccess) return fail(TAFL_ERR_HIP, "tafl_mcts: stream fork failed");
+            }
+            {
+                SpanGuard sg(c, KC_MCTS_ROLLOUT, pk.s);
+                uint32_t* tr = (k == 0 && i < TAFL_MCTS_TRACE_ROUNDS) ? (uint32_t*)b->trace.p + 2 * i : nullptr;      // the first partition's rounds are traced
+                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(pk.grid_roll), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->seed,
+                                                      sp.base, p->sim_offset, p->max_rollout_plies, pk.wl, wc_now, wc_next, pk.g1 - pk.g0, pk.cap, st, tr,
+                                                      k == 0 ? ctrl : nullptr, i, sp.planned, sp.probe_every));
+            }
+        }
+        stagger = false;
+        sp.next_round = i + 1;
+        if (!b->half_recorded && 2u * (i + 1u) >= sp.planned) {          // a search started "after" this one begins here (tafl_mcts_run_async_after)
+            if (hipEventRecord(b->ev_half, sp.P[0].s) != hipSuccess) return fail(TAFL_ERR_HIP, "tafl_mcts: hipEventRecord failed");
+            b->half_recorded = true;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return TAFL_OK;
+}
+static int mcts_enqueue_fused(tafl_batch* b, uint32_t rounds) {
+    tafl_ctx* c = b->ctx; SearchPlan& sp = b->plan; const tafl_mcts_params* p = &sp.p; const uint32_t n = b->n, bps = grid_of(n);
+    unsigned long long* st = (unsigned long long*)b->stats.p; const MctsMem& M = sp.M; hipStream_t s0 = sp.P[0].s;
+    SpanGuard sg(c, KC_MCTS_ROLLOUT, s0);
+    constexpr int NL = 2, W = 7; const Consts<2>& CC = c->c2;
+    if (c->preset == PRESET_BRANDUBH7) {
+        if (sp.slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
+        else hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
+    } else {
+        if (sp.slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
+        else hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
+    }
+    sp.next_round += rounds;
+    return TAFL_OK;
+}
+
+int tafl_mcts_wait(tafl_batch* b);
+
+static int mcts_begin(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base, tafl_batch* after) {
     if (!b || !p) return fail(TAFL_ERR_INVALID_ARG, "null argument");
     if (p->flags & ~(uint32_t)TAFL_MCTS_FLAGS_KNOWN) return fail(TAFL_ERR_UNSUPPORTED, "tafl_mcts_params.flags: unknown bits set");
     if (p->n_sims == 0) return fail(TAFL_ERR_INVALID_ARG, "n_sims must be > 0");
-    int rc = tafl_mcts_reserve(b, p->n_sims);
-    if (rc) return rc;
+    if (after && after->ctx->device != b->ctx->device) return fail(TAFL_ERR_INVALID_ARG, "tafl_mcts_run_async_after: the two batches live on different devices");
+    int rc = TAFL_OK;
+    if (b->plan.active && (rc = tafl_mcts_wait(b)) != TAFL_OK) return rc;       // one search per batch at a time
+    if ((rc = tafl_mcts_reserve(b, p->n_sims)) != TAFL_OK) return rc;
     tafl_ctx* c = b->ctx; const uint32_t n = b->n;
     HIPCHK(hipSetDevice(c->device));
-    MctsMem M = b->mem;
+    SearchPlan& sp = b->plan;
+    sp.p = *p; sp.base = game_id_base; sp.next_round = 0; sp.fused = false;
+    MctsMem& M = sp.M; M = b->mem;
     M.node_cap = p->n_sims + 1; M.edge_cap = b->mem.edge_cap; M.flags = p->flags & TAFL_MCTS_FLAG_FPU_INF;
-    unsigned long long* st = (unsigned long long*)b->stats.p;
-    HIPCHK(hipMemsetAsync(st, 0, sizeof(unsigned long long) * ST_COUNT, c->stream));
     // tuning fields of `flags` (results never depend on them): pipeline and playout slots per game
     const uint32_t pipe = TAFL_MCTS_TUNE_PIPELINE_OF(p->flags);
     uint32_t slots = TAFL_MCTS_TUNE_SLOTS_OF(p->flags);
@@ -960,177 +1085,143 @@ int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_bas
     // playout loop (256 VGPRs and spills) and the two-kernel pipeline is faster anyway (13x13: 44.9 M vs 37.4 M sims/s).
     if (pipe == TAFL_MCTS_PIPELINE_FUSED && c->nl != 2) return fail(TAFL_ERR_UNSUPPORTED, "the fused pipeline exists for 64-bit boards (word_bits 64) only");
     const bool fused = pipe == TAFL_MCTS_PIPELINE_FUSED || (pipe == TAFL_MCTS_PIPELINE_DEFAULT && c->nl == 2 && slots <= 2);
-    if (slots == 0) {
-        // enough playouts in flight for ~4 waves per SIMD (1024 SIMDs x 64 lanes): 4 slots per game at 65 536 games
-        slots = fused ? 2u : (uint32_t)((4ull * 65536ull + n - 1) / n);
-        if (slots < 2) slots = 2;
-    }
+    if (fused && slots == 0) slots = 2;
     if (fused && slots > 2) return fail(TAFL_ERR_UNSUPPORTED, "the fused pipeline has 1 or 2 playout slots per game");
-    if (slots > b->spec_k) slots = b->spec_k;
-    DISPATCH_ARENA(c, hipLaunchKernelGGL((k_mcts_init<NLS, WS, NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, M));
-    const uint32_t bps = grid_of(n);
-    uint32_t* wlist = (uint32_t*)b->work.p; uint32_t* wcount = (uint32_t*)b->work_count.p;
-    if (fused) {
-        // Fused pipeline (k_mcts_fused): one wave owns 64 / K games for a whole chunk of rounds; between chunks the host reads the
-        // counters (one sync) and stops when every game is done.
-        M.spec_k = slots;
-        uint32_t rounds_left = p->n_sims + 1, chunk_len = 8;
-        int rcode = TAFL_OK;
-        while (rounds_left > 0) {
-            const uint32_t rounds = chunk_len < rounds_left ? chunk_len : rounds_left;
-            {
-                SpanGuard sg(c, KC_MCTS_ROLLOUT);
-                constexpr int NL = 2, W = 7; const Consts<2>& CC = c->c2;
-                if (c->preset == PRESET_BRANDUBH7) {
-                    if (slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st);
-                    else hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st);
-                } else {
-                    if (slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st);
-                    else hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, c->stream, CC, M, p->c_puct, p->n_sims, p->seed, game_id_base, p->sim_offset, p->max_rollout_plies, rounds, st);
-                }
-            }
-            rounds_left -= rounds;
-            if (chunk_len < 16) chunk_len *= 2;
-            unsigned long long h[ST_COUNT];
-            if (hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rcode = fail(TAFL_ERR_HIP, "tafl_mcts_run: stats read-back failed"); break; }
-            if (h[ST_DONE] >= (unsigned long long)n) break;                         // every game has consumed its last playout
+    uint32_t capacity = 0;
+    if (!fused) {
+        if (c->rollout_capacity == 0) {
+            int blocks = 0; hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, c->device));
+            DISPATCH_ARENA_PRESET(c, { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_mcts_rollout<NL, W, PRESET>, TAFL_BLOCK, 0) != hipSuccess) blocks = 0; });
+            if (blocks < 1) blocks = 8;
+            c->rollout_capacity = (uint32_t)blocks * (uint32_t)prop.multiProcessorCount * TAFL_BLOCK;
         }
-        if (rcode) return rcode;
-        HIPCHK(hipGetLastError());
-        b->ran = true; b->trace_rounds = 0;
-        return TAFL_OK;
+        capacity = c->rollout_capacity;
+        if (slots == 0) {                                           // what fills the device exactly: 4 slots per game at 65 536 games on 11x11
+            slots = capacity / n;
+            if (slots < 1) slots = 1;
+        }
     }
-    // Two-kernel pipeline: per round one tree launch (one game per lane: backups, real selections, slot matching, prediction of the next
-    // slots, dense work list) and one playout launch over the work list (k_mcts_rollout: <= 128 VGPRs, 4 waves per SIMD).
-    // The search is planned for ceil(n_sims / slots) rounds; every game issues ceil(remaining / rounds left) slots, so games that lost a
-    // round to a misprediction catch up instead of trailing behind in nearly empty rounds.  Nothing is read back until the plan is
-    // through; then the counters are checked every few rounds (launches of a finished batch return at once).
-    M.spec_k = b->spec_k;
-    if (c->rollout_capacity == 0) {
-        int blocks = 0; hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, c->device));
-        DISPATCH_ARENA_PRESET(c, { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_mcts_rollout<NL, W, PRESET>, TAFL_BLOCK, 0) != hipSuccess) blocks = 0; });
-        if (blocks < 1) blocks = 8;
-        c->rollout_capacity = (uint32_t)blocks * (uint32_t)prop.multiProcessorCount * TAFL_BLOCK;
-    }
-    const uint32_t capacity = c->rollout_capacity;
-    if (TAFL_MCTS_TUNE_SLOTS_OF(p->flags) == 0) {               // what fills the device exactly: 4 slots per game at 65 536 games on 11x11
-        slots = capacity / n;
-        if (slots < 1) slots = 1;
-        if (slots > b->spec_k) slots = b->spec_k;
-    }
-    const uint32_t planned = (p->n_sims + slots - 1) / slots;
+    if (slots > b->spec_k) slots = b->spec_k;
+    sp.fused = fused; sp.slots = slots;
     // The batch is cut into partitions (two by default) that run the same pipeline on their own streams, started one tree launch apart: the
     // tree phase of a partition (latency- and divergence-bound, one wave per 64 games) then runs under the playouts of the others instead
     // of on an idle device, and the partitions' rounds interleave instead of ending together.  Each partition may fill its share of the
     // device.  Small batches stay in one piece.
-    uint32_t parts = n >= 8192u ? 2u : 1u;                      // measured at 65 536 games, S = 64: 1: 56.9, 2: 64.6, 3: 61.2, 4: 61.0, 8: 35.7 M sims/s
-    if (TAFL_MCTS_TUNE_PARTS_OF(p->flags)) { parts = TAFL_MCTS_TUNE_PARTS_OF(p->flags); if (parts > TAFL_MCTS_MAX_PARTS) parts = TAFL_MCTS_MAX_PARTS; }
+    uint32_t parts = (!fused && n >= 8192u) ? 2u : 1u;             // measured at 65 536 games, S = 64: 1: 56.9, 2: 64.6, 3: 61.2, 4: 61.0, 8: 35.7 M sims/s
+    if (!fused && TAFL_MCTS_TUNE_PARTS_OF(p->flags)) { parts = TAFL_MCTS_TUNE_PARTS_OF(p->flags); if (parts > TAFL_MCTS_MAX_PARTS) parts = TAFL_MCTS_MAX_PARTS; }
     if (parts > grid_of(n)) parts = grid_of(n);
-    if (c->n_part_streams == 0) { c->part_stream[0] = c->stream; c->n_part_streams = 1; }
-    while (c->n_part_streams < parts) {
-        const uint32_t k = c->n_part_streams;
-        HIPCHK(hipStreamCreateWithFlags(&c->part_stream[k], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_fork[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
-        c->n_part_streams = k + 1;
+    sp.parts = parts;
+    if ((rc = search_streams(b, parts)) != TAFL_OK) return rc;
+    // the search starts behind everything enqueued on the context's stream so far (uploads, steps ...) and, if asked for, behind the first
+    // half of another batch's search in flight
+    HIPCHK(hipEventRecord(b->ev_start, c->stream));
+    HIPCHK(hipStreamWaitEvent(b->sstream[0], b->ev_start, 0));
+    if (after && after != b && after->plan.active && after->half_recorded) HIPCHK(hipStreamWaitEvent(b->sstream[0], after->ev_half, 0));
+    b->half_recorded = false;
+    hipStream_t s0 = b->sstream[0];
+    unsigned long long* st = (unsigned long long*)b->stats.p;
+    HIPCHK(hipMemsetAsync(st, 0, sizeof(unsigned long long) * ST_COUNT, s0));
+    M.spec_k = fused ? slots : b->spec_k;
+    DISPATCH_ARENA(c, hipLaunchKernelGGL((k_mcts_init<NLS, WS, NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, s0, CC, b->soa, M));
+    b->ran = false; b->trace_rounds = 0;
+    if (fused) {
+        // Fused pipeline (k_mcts_fused): one wave owns 64 / K games for a whole chunk of rounds and leaves as soon as its games are done;
+        // n_sims + 1 rounds always suffice (every round completes at least one simulation of every live game)
+        sp.P[0].s = s0; sp.planned = p->n_sims + 1; sp.max_rounds = p->n_sims + 1; sp.probe_every = 0;
+        uint32_t left = p->n_sims + 1, chunk_len = 8;
+        while (left > 0) {
+            const uint32_t rounds = chunk_len < left ? chunk_len : left;
+            if ((rc = mcts_enqueue_fused(b, rounds)) != TAFL_OK) return rc;
+            left -= rounds;
+            if (chunk_len < 16) chunk_len *= 2;
+            if (!b->half_recorded && 2u * sp.next_round >= sp.planned) { HIPCHK(hipEventRecord(b->ev_half, s0)); b->half_recorded = true; }
+        }
+        HIPCHK(hipGetLastError());
+        sp.active = true;
+        return TAFL_OK;
     }
-    c->part_stream[0] = c->stream;
-    struct Part { uint32_t g0, g1, cap, grid_tree, grid_roll; hipStream_t s; uint32_t* wl; uint32_t* wc; };
-    Part P[TAFL_MCTS_MAX_PARTS];
+    // Two-kernel pipeline.  The search is planned for ceil(n_sims / slots) rounds; every game issues ceil(remaining / rounds left) slots, so
+    // games that lost a round to a misprediction catch up instead of trailing behind in nearly empty rounds.
+    const uint32_t planned = (p->n_sims + slots - 1) / slots;
+    uint32_t* wlist = (uint32_t*)b->work.p; uint32_t* wcount = (uint32_t*)b->work_count.p;
     {
         const uint32_t waves = grid_of(n), per = waves / parts, extra = waves % parts;
         uint32_t w0 = 0; size_t wl_off = 0;
         for (uint32_t k = 0; k < parts; ++k) {
+            SearchPart& P = sp.P[k];
             const uint32_t wk = per + (k < extra ? 1u : 0u);
-            P[k].g0 = w0 * TAFL_BLOCK; P[k].g1 = (w0 + wk) * TAFL_BLOCK < n ? (w0 + wk) * TAFL_BLOCK : n;
+            P.g0 = w0 * TAFL_BLOCK; P.g1 = (w0 + wk) * TAFL_BLOCK < n ? (w0 + wk) * TAFL_BLOCK : n;
             w0 += wk;
-            const uint32_t cnt = P[k].g1 - P[k].g0;
-            P[k].cap = parts > 1 ? (uint32_t)((unsigned long long)capacity * cnt / n / TAFL_BLOCK * TAFL_BLOCK) : capacity;
-            if (P[k].cap < TAFL_BLOCK) P[k].cap = TAFL_BLOCK;
+            const uint32_t cnt = P.g1 - P.g0;
+            P.cap = parts > 1 ? (uint32_t)((unsigned long long)capacity * cnt / n / TAFL_BLOCK * TAFL_BLOCK) : capacity;
+            if (P.cap < TAFL_BLOCK) P.cap = TAFL_BLOCK;
             const unsigned long long most = (unsigned long long)cnt * M.spec_k;
-            P[k].grid_tree = grid_of(cnt);
-            P[k].grid_roll = (uint32_t)(((most < P[k].cap ? most : P[k].cap) + TAFL_BLOCK - 1) / TAFL_BLOCK);
-            P[k].s = c->part_stream[k];
-            P[k].wl = wlist + wl_off; wl_off += (size_t)cnt * M.spec_k;
-            P[k].wc = wcount + (size_t)k * 2 * TAFL_MCTS_MAX_SLOTS;              // two counter sets per partition: the playout launch of a round clears the next round's
+            P.grid_tree = grid_of(cnt);
+            P.grid_roll = (uint32_t)(((most < P.cap ? most : P.cap) + TAFL_BLOCK - 1) / TAFL_BLOCK);
+            P.s = b->sstream[k];
+            P.wl = wlist + wl_off; wl_off += (size_t)cnt * M.spec_k;
+            P.wc = wcount + (size_t)k * 2 * TAFL_MCTS_MAX_SLOTS;              // two counter sets per partition: the playout launch of a round clears the next round's
         }
     }
-    // every round runs min(capacity, requested) playouts, slot 0 of every waiting game first: progress is guaranteed, and the loop ends
-    // as soon as the counters say so
-    // first read-back of a short search: a large batch always has stragglers that need a few rounds more than the plan (65 536 games: 5 - 6),
-    // and a read-back drains both streams (~0.1 ms) while launches for a finished batch return at once
-    const uint32_t tail_guess = n >= 32768u ? 5u : n >= 4096u ? 3u : n >= 512u ? 1u : 0u;
+    // every round runs min(capacity, requested) playouts, slot 0 of every waiting game first: progress is guaranteed
+    // a large batch always has stragglers that need a few rounds more than the plan (65 536 games: 5 - 6)
+    const uint32_t tail_guess = n >= 32768u ? 6u : n >= 4096u ? 4u : n >= 512u ? 2u : 1u;
     const unsigned long long rounds_bound = ((unsigned long long)p->n_sims + 2 + tail_guess) * (1 + (unsigned long long)n / (capacity ? capacity : 1));
-    const uint32_t max_rounds = rounds_bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rounds_bound;
-    // Long searches are also read back every 16 rounds before the plan is through: the share of predictions that came true since the last
-    // read-back sets how many predicted simulations a game may run beside the pending one (a prediction costs a child expansion in the
-    // tree phase and, when it fails, a playout: S = 1000 runs 50.6 M sims/s with the thresholds below, 45.5 M when the windows with
-    // 45 - 75 % hits get three predictions instead of one, S = 256 63.8 M with them and 62.0 M with narrower ones).
-    const uint32_t probe_every = planned >= 64 ? 16u : 0u;
-    uint32_t next_check = probe_every ? probe_every : planned + 1 + tail_guess, wcap = M.spec_k - 1;
-    unsigned long long last_hits = 0, last_issued = 0, done_games = 0;
-    HIPCHK(hipMemsetAsync(b->trace.p, 0, 8 * TAFL_MCTS_TRACE_ROUNDS, c->stream));
-    HIPCHK(hipMemsetAsync(wcount, 0, sizeof(uint32_t) * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS, c->stream));
-    b->trace_rounds = 0;
-    // partition k starts behind partition k-1's tree launch (and again after every read-back): from then on the tree phases are spread over a round
-    bool stagger = parts > 1;
-    int rcode = TAFL_OK;
-    for (uint32_t i = 0; i < max_rounds && rcode == TAFL_OK; ++i) {
-        // past the plan: 1 = "use every slot that exists" (wasted playouts are free on an emptying device) for short searches and, for long
-        // ones, once three quarters of the games are done; until then 0 = every game keeps to what its own hit history allows (a long search
-        // whose predictions fail runs far beyond the plan with every game still alive: S = 1000 runs 44 M sims/s this way, 39 M otherwise)
-        const uint32_t rounds_left = i < planned ? planned - i : ((probe_every == 0 || 4ull * done_games >= 3ull * n) ? 1u : 0u);
-        b->trace_rounds = i + 1;
-        for (uint32_t k = 0; k < parts && rcode == TAFL_OK; ++k) {
-            const Part& pk = P[k];
-            uint32_t* wc_now = pk.wc + (i & 1u) * TAFL_MCTS_MAX_SLOTS; uint32_t* wc_next = pk.wc + ((i + 1u) & 1u) * TAFL_MCTS_MAX_SLOTS;
-            {
-                SpanGuard sg(c, KC_MCTS_TREE, pk.s);
-                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->c_puct, p->n_sims, rounds_left, slots, wcap, st,
-                                                      pk.wl, wc_now, wc_next, pk.cap, pk.g0, pk.g1));
-            }
-            if (stagger && k + 1 < parts) {       // the next partition's fork event must sit right behind this tree launch
-                if (hipEventRecord(c->ev_fork[k + 1], pk.s) != hipSuccess || hipStreamWaitEvent(P[k + 1].s, c->ev_fork[k + 1], 0) != hipSuccess) { rcode = fail(TAFL_ERR_HIP, "tafl_mcts_run: stream fork failed"); break; }
-            }
-            {
-                SpanGuard sg(c, KC_MCTS_ROLLOUT, pk.s);
-                uint32_t* tr = (k == 0 && i < TAFL_MCTS_TRACE_ROUNDS) ? (uint32_t*)b->trace.p + 2 * i : nullptr;      // the first partition's rounds are traced
-                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_rollout<NL, W, PRESET>), dim3(pk.grid_roll), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->seed,
-                                                      game_id_base, p->sim_offset, p->max_rollout_plies, pk.wl, wc_now, wc_next, pk.g1 - pk.g0, pk.cap, st, tr));
-            }
-        }
-        stagger = false;
-        if (i + 1 >= next_check && rcode == TAFL_OK) {
-            unsigned long long h[ST_COUNT];
-            for (uint32_t k = 1; k < parts; ++k)
-                if (hipEventRecord(c->ev_join[k], P[k].s) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_join[k], 0) != hipSuccess) { rcode = fail(TAFL_ERR_HIP, "tafl_mcts_run: stream join failed"); break; }
-            if (rcode) break;
-            if (hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rcode = fail(TAFL_ERR_HIP, "tafl_mcts_run: stats read-back failed"); break; }
-            if (h[ST_DONE] >= (unsigned long long)n) break;                         // every game has consumed its last playout
-            done_games = h[ST_DONE];
-            if (probe_every) {
-                const unsigned long long di = h[ST_SPEC_ISSUED] - last_issued, dh = h[ST_SPEC_HITS] - last_hits;
-                last_issued = h[ST_SPEC_ISSUED]; last_hits = h[ST_SPEC_HITS];
-                if (di > (unsigned long long)n / 4) {
-                    const double hit = (double)dh / (double)di;
-                    wcap = hit > 0.85 ? M.spec_k - 1 : hit > 0.75 ? 3u : hit > 0.70 ? 2u : 1u;      // A/B on S = 256 / 1000
-                } else wcap = wcap < M.spec_k - 1 ? wcap + 1 : wcap;              // hardly anything was predicted: probe one wider
-            }
-            next_check = i + 1 + (i + 1 < planned && probe_every ? probe_every : (planned >= 32 ? 4u : 2u));
-            stagger = parts > 1;
-        }
+    sp.max_rounds = rounds_bound > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rounds_bound;
+    sp.planned = planned;
+    // long searches: width control every 16 rounds (k_mcts_rollout)
+    sp.probe_every = planned >= 64 ? 16u : 0u;
+    sp.ctrl0[CT_WCAP] = M.spec_k - 1u; sp.ctrl0[CT_LAST_ISSUED] = sp.ctrl0[CT_LAST_HITS] = 0ull; sp.ctrl0[CT_NEXT_CHECK] = sp.probe_every ? sp.probe_every : ~0ull;
+    HIPCHK(hipMemcpyAsync(b->ctrl.p, sp.ctrl0, sizeof sp.ctrl0, hipMemcpyHostToDevice, s0));      // (the source lives in the batch until the search is joined)
+    HIPCHK(hipMemsetAsync(b->trace.p, 0, 8 * TAFL_MCTS_TRACE_ROUNDS, s0));
+    HIPCHK(hipMemsetAsync(wcount, 0, sizeof(uint32_t) * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS, s0));
+    uint32_t first = planned + tail_guess;
+    if (first > sp.max_rounds) first = sp.max_rounds;
+    if ((rc = mcts_enqueue_rounds(b, first, parts > 1)) != TAFL_OK) return rc;
+    sp.active = true;
+    return TAFL_OK;
+}
+
+int tafl_mcts_run_async(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base) { return mcts_begin(b, p, game_id_base, nullptr); }
+int tafl_mcts_run_async_after(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base, tafl_batch* other) { return mcts_begin(b, p, game_id_base, other); }
+
+int tafl_mcts_wait(tafl_batch* b) {
+    if (!b) return fail(TAFL_ERR_INVALID_ARG, "null batch");
+    SearchPlan& sp = b->plan;
+    if (!sp.active) return b->ran ? TAFL_OK : fail(TAFL_ERR_INVALID_ARG, "tafl_mcts_wait: no search was started on this batch");
+    tafl_ctx* c = b->ctx; const uint32_t n = b->n;
+    HIPCHK(hipSetDevice(c->device));
+    sp.active = false;                                                      // whatever happens below, the plan is over
+    for (;;) {
+        for (uint32_t k = 0; k < sp.parts; ++k) HIPCHK(hipStreamSynchronize(sp.P[k].s));
+        unsigned long long h[ST_COUNT];
+        HIPCHK(hipMemcpyAsync(h, b->stats.p, sizeof h, hipMemcpyDeviceToHost, sp.P[0].s));
+        HIPCHK(hipStreamSynchronize(sp.P[0].s));
+        if (h[ST_DONE] >= (unsigned long long)n) break;                     // every game has consumed its last playout
+        if (sp.fused) return fail(TAFL_ERR_HIP, "tafl_mcts_wait: the fused search ended with unfinished games");
+        // stragglers: a few more rounds, then look again (a round of a nearly finished batch is a lone wave per partition)
+        const int rc = mcts_enqueue_rounds(b, sp.planned >= 32 ? 4u : 2u, false);
+        if (rc) return rc;
     }
-    // whatever happened, the caller's stream must be ordered after the others before the batch is used again
-    for (uint32_t k = 1; k < parts; ++k) { (void)hipEventRecord(c->ev_join[k], P[k].s); (void)hipStreamWaitEvent(c->stream, c->ev_join[k], 0); }
-    if (rcode) return rcode;
-    HIPCHK(hipGetLastError());
     b->ran = true;
     return TAFL_OK;
 }
 
+int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base) {
+    const int rc = mcts_begin(b, p, game_id_base, nullptr);
+    return rc ? rc : tafl_mcts_wait(b);
+}
+
+// every reader of a search's results joins a search in flight first; non-zero = there is no finished search to read
+static int search_done(tafl_batch* b) {
+    if (b->plan.active && tafl_mcts_wait(b) != TAFL_OK) return 1;
+    return b->ran ? 0 : 1;
+}
+
 // measurement: playouts requested / run in every round of the last two-kernel search (0 rounds after a fused search)
 int tafl_mcts_round_trace(tafl_batch* b, uint32_t* requested, uint32_t* run, uint32_t cap, uint32_t* n_rounds) {
-    if (!b || !n_rounds || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!b || !n_rounds || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
     tafl_ctx* c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     const uint32_t k = b->trace_rounds < TAFL_MCTS_TRACE_ROUNDS ? b->trace_rounds : TAFL_MCTS_TRACE_ROUNDS;
@@ -1142,7 +1233,7 @@ int tafl_mcts_round_trace(tafl_batch* b, uint32_t* requested, uint32_t* run, uin
 }
 
 int tafl_mcts_get_stats(tafl_batch* b, tafl_mcts_stats* out) {
-    if (!b || !out || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "no MCTS run on this batch");
+    if (!b || !out || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "no MCTS run on this batch");
     tafl_ctx* c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     unsigned long long h[ST_COUNT];
@@ -1157,7 +1248,7 @@ int tafl_mcts_get_stats(tafl_batch* b, tafl_mcts_stats* out) {
 }
 
 int tafl_mcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_children, uint32_t* out_n) {
-    if (!b || !out || !out_n || max_children == 0 || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!b || !out || !out_n || max_children == 0 || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
     tafl_ctx* c = b->ctx; const uint32_t n = b->n;
     HIPCHK(hipSetDevice(c->device));
     NEED(b->children, sizeof(tafl_root_child) * (size_t)n * max_children); NEED(b->children_n, sizeof(uint32_t) * n);
@@ -1173,7 +1264,7 @@ int tafl_mcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_ch
 }
 
 int tafl_mcts_root_visits(tafl_batch* b, uint32_t* out) {
-    if (!b || !out || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!b || !out || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
     tafl_ctx* c = b->ctx; const uint32_t n = b->n, as = tafl_action_size(c);
     HIPCHK(hipSetDevice(c->device));
     NEED(b->visits, sizeof(uint32_t) * (size_t)n * as);
@@ -1187,7 +1278,7 @@ int tafl_mcts_root_visits(tafl_batch* b, uint32_t* out) {
 
 // probs of src/mcts.py:40-53 computed on the host from the device's root visit counts (float64, same op order)
 int tafl_mcts_policy(tafl_batch* b, double temp, double* out) {
-    if (!b || !out || !b->ran || temp < 0) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!b || !out || search_done(b) || temp < 0) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
     tafl_ctx* c = b->ctx; const uint32_t n = b->n, as = tafl_action_size(c);
     std::vector<uint32_t> counts((size_t)n * as);
     int rc = tafl_mcts_root_visits(b, counts.data());
@@ -1209,7 +1300,7 @@ int tafl_mcts_policy(tafl_batch* b, double temp, double* out) {
 }
 
 int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visits) {
-    if (!b || !out_plays || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!b || !out_plays || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
     tafl_ctx* c = b->ctx; const uint32_t n = b->n;
     HIPCHK(hipSetDevice(c->device));
     NEED(b->best_plays, sizeof(tafl_play) * n); NEED(b->best_visits, sizeof(uint32_t) * n);
@@ -1223,7 +1314,7 @@ int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visit
 }
 
 int tafl_mcts_play_best(tafl_batch* b, tafl_play* out_plays, tafl_effects* out_effects) {
-    if (!b || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!b || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
     tafl_ctx* c = b->ctx; const uint32_t n = b->n;
     HIPCHK(hipSetDevice(c->device));
     if (out_plays) NEED(b->best_plays, sizeof(tafl_play) * n);
@@ -1253,7 +1344,7 @@ int tafl_encode_boards(tafl_batch* b, uint8_t* out, int out_is_device) {
 }
 
 int tafl_mcts_policy_device_ex(tafl_batch* b, double temp, uint64_t tie_seed, uint64_t game_id_base, double* out, int out_is_device) {
-    if (!b || !out || !b->ran) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!b || !out || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
     if (!(temp >= 0.0)) return fail(TAFL_ERR_INVALID_ARG, "temp must be >= 0");
     tafl_ctx* c = b->ctx; const uint32_t n = b->n, as = tafl_action_size(c); const size_t bytes = sizeof(double) * (size_t)n * as;
     HIPCHK(hipSetDevice(c->device));

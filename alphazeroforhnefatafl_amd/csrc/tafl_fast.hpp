@@ -60,6 +60,9 @@ struct FastConsts {
     Bits<NL> lfs[2], lfsr[2];  // landing forbidden: attacker soldier, defender soldier
     Bits<NL> lfk, lfkr;      // landing forbidden: king
     Bits<NL> edge, edger;
+    // the king's plays from the soldiers' fill (Fast::gen): possible when every tile open to a defender soldier is open to the king too;
+    // ks_corner / ks_throne: ... and the king may, unlike the soldiers, stop on the corners / on the throne
+    bool king_lines, ks_corner, ks_throne;
 };
 template <int NL>
 constexpr FastConsts<NL> make_fast_consts(const Consts<NL>& C) {
@@ -73,6 +76,14 @@ constexpr FastConsts<NL> make_fast_consts(const Consts<NL>& C) {
     }
     F.vbr = rev_ct<NL>(C.coln); F.emr = rev_ct<NL>(emr_n);
     F.lfsr[0] = rev_ct<NL>(F.lfs[0]); F.lfsr[1] = rev_ct<NL>(F.lfs[1]); F.lfkr = rev_ct<NL>(F.lfk); F.edger = rev_ct<NL>(F.edge);
+    F.king_lines = true; F.ks_corner = false; F.ks_throne = false;
+    for (int i = 0; i < NL; ++i) {
+        if (F.lfk.w[i] & ~F.lfs[1].w[i]) F.king_lines = false;
+        const uint32_t only_king = F.lfs[1].w[i] & ~F.lfk.w[i];
+        if (only_king & C.corners.w[i]) F.ks_corner = true;
+        if (only_king & C.throne.w[i]) F.ks_throne = true;
+        if (only_king & ~(C.corners.w[i] | C.throne.w[i])) F.king_lines = false;       // (cannot happen: land_forbid is made of corners and throne)
+    }
     return F;
 }
 template <int NL>
@@ -111,13 +122,50 @@ struct Fast {
         // soldiers and king separately: they differ only in the tiles they may stop on (pieces of either kind block alike)
         return andn(fill(occ, andn(mine, kbit), vblock) & open, lfs) | andn(fill(occ, kbit, vblock) & open, lfk);
     }
+    // n (<= 15) bits of `a` from bit `base`
+    static TAFL_HD uint32_t line_bits(const B& a, uint32_t base, uint32_t n) { return (uint32_t)field64<0>(a, base) & ((1u << n) - 1u); }
+
+    // The king's plays onto the tiles only he may stop on (corners, throne): FastConsts::king_lines.  Everywhere else the king moves like a
+    // defender soldier (fast_ok: every piece may cross the empty throne), so gen() lets him slide with the soldiers in ONE fill per direction
+    // - with `~lfs` taking the special tiles out of the result - and adds here what only he may do: a special tile lies at the end of an
+    // edge line (corner) or in the middle of the centre line (throne), the king reaches it iff he stands on that line and every tile from
+    // his neighbour up to and including the target is empty.  Lines are read from the layout in which they are contiguous (rows from N,
+    // columns from T), at the three fixed positions 0, n/2, n-1.  At most twelve (tile, direction) pairs, each one bit of one limb for a
+    // preset (the indices are literals then) - instead of four more 128-bit subtraction fills for a single piece.
+    static TAFL_HD void king_specials(const S& st, const B& occN, const B& occT, const K& C, const F& fc, B r[4]) {
+        const uint32_t kr = TAFL_F_KROW(st.flags), kc = TAFL_F_KCOL(st.flags), n = C.n, L = n - 1u, c = div_w<W>(C.throne_sq);
+        const uint32_t lw = mul24(L, (uint32_t)W), cw = mul24(c, (uint32_t)W);
+        const bool kp = kr < n && kc < n && test(st.def, mul24(kr, (uint32_t)W) + kc);      // the king is on the board
+        const uint32_t rowocc = kr == 0u ? line_bits(occN, 0u, n) : kr == c ? line_bits(occN, cw, n) : line_bits(occN, lw, n);
+        const uint32_t colocc = kc == 0u ? line_bits(occT, 0u, n) : kc == c ? line_bits(occT, cw, n) : line_bits(occT, lw, n);
+        const uint32_t lo_r = rowocc & ((1u << kc) - 1u), hi_r = rowocc >> (kc + 1u);      // the row below / above the king's column
+        const uint32_t lo_c = colocc & ((1u << kr) - 1u), hi_c = colocc >> (kr + 1u);      // the column below / above the king's row
+        auto put = [](B& set, uint32_t idx, bool cond) { set |= gate(bit_at<NL>(idx), cond); };
+        if (fc.ks_corner) {
+            const bool r0 = kp && kr == 0u, rL = kp && kr == L, c0 = kp && kc == 0u, cL = kp && kc == L;
+            const bool hm = kc > 0u && lo_r == 0u, hp = kc < L && hi_r == 0u, vm = kr > 0u && lo_c == 0u, vp = kr < L && hi_c == 0u;
+            put(r[3], Z, r0 && hm);             put(r[3], Z - lw, rL && hm);          // H-: (kr, 0), reversed N index
+            put(r[2], L, r0 && hp);             put(r[2], lw + L, rL && hp);          // H+: (kr, n-1)
+            put(r[1], Z, c0 && vm);             put(r[1], Z - lw, cL && vm);          // V-: (0, kc), reversed T index (bit = col * W + row)
+            put(r[0], L, c0 && vp);             put(r[0], lw + L, cL && vp);          // V+: (n-1, kc)
+        }
+        if (fc.ks_throne) {
+            const bool rc = kp && kr == c, cc = kp && kc == c;
+            put(r[2], cw + c, rc && kc < c && (hi_r & ((1u << ((c - kc) & 31u)) - 1u)) == 0u);     // columns kc+1 .. c empty
+            put(r[3], Z - (cw + c), rc && kc > c && (lo_r >> c) == 0u);                            // columns c .. kc-1 empty
+            put(r[0], cw + c, cc && kr < c && (hi_c & ((1u << ((c - kr) & 31u)) - 1u)) == 0u);
+            put(r[1], Z - (cw + c), cc && kr > c && (lo_c >> c) == 0u);
+        }
+    }
+
     static TAFL_HD void gen(const S& st, const B& attT, const B& defT, uint32_t side, const K& C, const F& fc, Gen& g) {
         const B occN = (st.att | st.def) & C.board, occT = (attT | defT) & C.board;
         const B mineN = (side ? st.def : st.att) & C.board, mineT = (side ? defT : attT) & C.board;
         const uint32_t k = E::king_sq(st, C);
         B kN = bz<NL>(), kT = bz<NL>();
-        // the king's own rays are needed only where a defender is to move: skipped when no game of the wave is in that case
-        const bool any_king_lane = wave_any(side != 0 && k != TAFL_NO_SQ);
+        // the king's own rays are needed only where a defender is to move (and only under rules that do not allow king_specials):
+        // skipped when no game of the wave is in that case
+        const bool any_king_lane = !fc.king_lines && wave_any(side != 0 && k != TAFL_NO_SQ);
         if (any_king_lane) {
             const bool kalive = side && k != TAFL_NO_SQ;
             const uint32_t ks = kalive ? k : 0u;
@@ -128,6 +176,7 @@ struct Fast {
         g.r[1] = reach1(rev(occT), rev(mineT), rev(kT), fc.vbr, fc.emr, lfsr, fc.lfkr, any_king_lane);
         g.r[2] = reach1(occN, mineN, kN, fc.vb, fc.em, lfs, fc.lfk, any_king_lane);
         g.r[3] = reach1(rev(occN), rev(mineN), rev(kN), fc.vbr, fc.emr, lfsr, fc.lfkr, any_king_lane);
+        if (side != 0 && fc.king_lines && (fc.ks_corner || fc.ks_throne)) king_specials(st, occN, occT, C, fc, g.r);
         g.total = 0;
         TAFL_UNROLL for (int d = 0; d < 4; ++d) { g.cnt[d] = popc(g.r[d]); g.total += g.cnt[d]; }
         // (only the enclosure filter reads it: behind an attacker's play, i.e. for a defender's move set)
@@ -174,9 +223,6 @@ struct Fast {
     // holds for one defender ply in ~10^3 (tools/playout_event_stats.py), so that the rings and the flood of Engine::exit_fort - paid by
     // every wave on every defender ply before - are entered by a wave only now and then.  The line is read from the layout in which it is
     // contiguous: rows 0 / n-1 from N, columns 0 / n-1 from T (= rows 0 / n-1 of T).
-    static TAFL_HD uint32_t line_bits(const B& a, uint32_t base, uint32_t n) {         // n <= 15 bits of `a` from bit `base`
-        return (uint32_t)field64<0>(a, base) & ((1u << n) - 1u);
-    }
     static TAFL_HD bool fort_candidate(const S& st, const B& attT, const B& defT, const K& C) {
         const uint32_t kr = TAFL_F_KROW(st.flags), kc = TAFL_F_KCOL(st.flags), n = C.n, last = n - 1u, lb = mul24(last, (uint32_t)W);
         const bool top = kr == 0u, bot = kr == last, lef = kc == 0u, rig = kc == last;

@@ -175,6 +175,22 @@ class GameBatch:
         p = TaflMctsParams(n_sims, max_rollout_plies, c_puct, seed, sim_offset, flags)
         check(lib().tafl_mcts_run(self._h, C.byref(p), game_id_base))
 
+    def mcts_run_async(self, n_sims: int, c_puct: float, seed: int, max_rollout_plies: int, game_id_base: int = 0,
+                       sim_offset: int = 0, flags: int = 0, after: "GameBatch | None" = None):
+        """The same search, enqueued on the batch's own streams without blocking the host (tafl_mcts_run_async): the search of another batch,
+        a network, or the bookkeeping of the previous move run beside it.  `after`: hold this search back until that batch's search in
+        flight is half-way through (two half-size batches started this way stay half a search apart, so that the nearly empty last rounds
+        of one run under the full rounds of the other).  Join with mcts_wait(); every reader of the results joins by itself."""
+        p = TaflMctsParams(n_sims, max_rollout_plies, c_puct, seed, sim_offset, flags)
+        if after is None:
+            check(lib().tafl_mcts_run_async(self._h, C.byref(p), game_id_base))
+        else:
+            check(lib().tafl_mcts_run_async_after(self._h, C.byref(p), game_id_base, after._h))
+
+    def mcts_wait(self):
+        """Joins the search in flight; runs the rounds its slowest games still need (tafl_mcts_wait)."""
+        check(lib().tafl_mcts_wait(self._h))
+
     def mcts_round_trace(self, cap: int = 4096):
         """(requested, run) playouts of every round of the last search (measurement; the two-kernel pipeline only)."""
         req, run, k = (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), C.c_uint32()

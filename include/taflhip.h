@@ -324,6 +324,20 @@ int tafl_random_advance(tafl_batch* b, uint64_t seed, const uint32_t* plies, uin
  */
 int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims);
 int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* params, uint64_t game_id_base);
+/* The same search without blocking the host (SURVEY 8b "calls enqueue ... asynchronous until tafl_sync"): tafl_mcts_run_async enqueues the
+ * whole search on streams of the BATCH and returns; nothing is read back while it runs (plan and prediction width are steered on the
+ * device).  tafl_mcts_wait joins it - and, while games are unfinished, runs the rounds its slowest games still need - so a search
+ * always completes or the call fails.  tafl_mcts_run == tafl_mcts_run_async + tafl_mcts_wait; per-game results are identical.
+ * Every reader of the results (root_children, root_visits, policy*, best_play, play_best, get_stats, round_trace) joins a search in
+ * flight by itself.  One search per batch at a time (a second run_async first joins the first); DIFFERENT batches of one context search
+ * side by side: the last rounds of a search are nearly empty (a few games whose simulations could not be predicted), and the device is
+ * kept busy by another batch's full rounds.  tafl_mcts_run_async_after(b, ..., other) additionally holds b's search back until `other`'s
+ * search in flight is half-way through its planned rounds (no effect if `other` has none): two half-size batches started this way stay
+ * half a search apart, the steady state of a self-play loop `wait(A); play(A); run_async(A); wait(B); play(B); run_async(B)`.
+ * The batch must not be modified (upload, step, reset) between run_async and wait. */
+int tafl_mcts_run_async(tafl_batch* b, const tafl_mcts_params* params, uint64_t game_id_base);
+int tafl_mcts_run_async_after(tafl_batch* b, const tafl_mcts_params* params, uint64_t game_id_base, tafl_batch* other);
+int tafl_mcts_wait(tafl_batch* b);
 int tafl_mcts_get_stats(tafl_batch* b, tafl_mcts_stats* out);
 int tafl_mcts_root_children(tafl_batch* b, tafl_root_child* out, uint32_t max_children, uint32_t* out_n);
 int tafl_mcts_root_visits(tafl_batch* b, uint32_t* out);

@@ -15,6 +15,8 @@ CONFIGS = {
     "koch7": (abi.rules.KOCH, abi.boards.BRANDUBH, 64),
     "copenhagen13": (abi.rules.COPENHAGEN, abi.boards.COPENHAGEN13, 256),
     "copenhagen9_u256": (abi.rules.COPENHAGEN, abi.boards.TABLUT, 256),
+    # a 13x13 board under rules that are NOT the Copenhagen preset: the run-time-rules kernels of the 256-bit word (8 limbs, 15 columns)
+    "tablut13_u256": (abi.rules.TABLUT, abi.boards.COPENHAGEN13, 256),
 }
 
 

@@ -209,7 +209,9 @@ def test_random_rulesets(seed):
 
 
 @pytest.mark.parametrize("name,G,cap", [("copenhagen11", 1024, 512), ("brandubh7", 512, 256), ("tablut9", 512, 300),
-                                       ("copenhagen13", 256, 300), ("magpie7", 256, 200)])
+                                       ("copenhagen13", 256, 300), ("magpie7", 256, 200),
+                                       # the 256-bit word WITHOUT the dense 13-column preset layout: k_rollout<8,15,8,15,0>
+                                       ("copenhagen9_u256", 256, 300), ("tablut13_u256", 192, 300)])
 def test_rollouts(name, G, cap):
     rules, fen, wb, n, lg = _mk(name)
     states = pu.start_states(orc, fen, rules.starting_side, wb, G)
@@ -350,13 +352,23 @@ def test_mcts_matches_reference_mcts_py_golden(case):
 
 @pytest.mark.parametrize("name,G,sims,cpuct,cap", [("copenhagen11", 64, 64, 1.0, 512), ("brandubh7", 128, 200, 1.0, 256),
                                                   ("tablut9", 64, 96, 1.5, 300), ("copenhagen13", 32, 32, 1.0, 256),
-                                                  ("copenhagen13", 6, 190, 1.0, 48), ("copenhagen11", 6, 400, 1.0, 48)])
+                                                  ("copenhagen13", 6, 190, 1.0, 48), ("copenhagen11", 6, 400, 1.0, 48),
+                                                  # run-time-rules kernels of the 256-bit word: k_mcts_tree / k_mcts_rollout<8,15,0>
+                                                  ("copenhagen9_u256", 32, 48, 1.0, 200), ("tablut13_u256", 16, 32, 1.0, 200),
+                                                  # c_puct == 0: an unvisited action TIES a visited one with Qsa == 0 (mcts.py:117-119)
+                                                  ("brandubh7", 64, 200, 0.0, 256), ("copenhagen11", 16, 120, 0.0, 64),
+                                                  # mixed mid-game positions (the config-1 input recipe) at the bench's S = 64 / cap 512
+                                                  ("copenhagen11:mid", 48, 64, 1.0, 512)])
 def test_mcts_vs_oracle(name, G, sims, cpuct, cap):
     """BASELINE config 3 parity: a fixed subset of games reproduced by the CPU oracle bit for bit.  (The two long searches: a root that
     grows past the 128 edges whose Qsa signs the tree step caches - 13x13 has 152 legal plays at the start - and deep trees.)"""
+    name, _, variant = name.partition(":")
     rules, fen, wb, n, lg = _mk(name)
     states = pu.start_states(orc, fen, rules.starting_side, wb, G)
-    if name != "copenhagen11":
+    if variant == "mid":
+        plies = (C.c_uint32 * G)(*[(i * 7 + 3) % 64 for i in range(G)])
+        orc.batch_random_advance(lg, states, G, wb, 1, plies, 77)
+    elif name != "copenhagen11":
         plies = (C.c_uint32 * G)(*[(i * 5) % 40 for i in range(G)])
         orc.batch_random_advance(lg, states, G, wb, 11, plies, 77)
     p = TaflMctsParams(sims, cap, cpuct, 2, 0, 0)
@@ -437,6 +449,110 @@ def test_full_size_properties_65536():
     oneres = orc.batch_rollout(lg, one, 1, wb, 7, 0, 512, 4097)
     assert (oneres[0].value, oneres[0].reason, oneres[0].plies) == (res[4097].value, res[4097].reason, res[4097].plies)
     assert pu.states_equal(pu.start_states(orc, fen, rules.starting_side, wb, 64), big.download(0, 64), 64)
+
+
+def _kids(kids, cnt, g, width):
+    return [(kids[g * width + j].action, kids[g * width + j].visits, float(kids[g * width + j].q).hex()) for j in range(cnt[g])]
+
+
+def _oracle_kids(lg, state, wb, p, gid):
+    one = (TaflState * 1)(state)
+    ok, on, _ = orc.batch_mcts(lg, one, 1, wb, p, gid)
+    return [(ok[j].action, ok[j].visits, float(ok[j].q).hex()) for j in range(on[0])]
+
+
+def test_long_search_with_device_side_width_control_vs_oracle():
+    """S = 300 at four slots per game is planned for 75 rounds (>= 64): the width cap of the prediction pass is then steered on the device
+    from the hit rate of the last 16 rounds (k_mcts_rollout, CT_WCAP), two partitions run on two streams, and the stragglers' rounds are
+    run by tafl_mcts_wait.  8 192 games from mixed mid-game positions; scattered ids against the oracle, all counters conserved."""
+    rules, fen, wb, n, lg = _mk("copenhagen11")
+    G, sims, cap, seed, base = 8192, 300, 96, 9, 1000
+    b = gpu_logic(rules, n, wb).new_batch(G, fen)
+    plies = (C.c_uint32 * G)(*[i % 64 for i in range(G)])
+    b.random_advance(1, plies, base)
+    states = b.download()
+    b.mcts_run(sims, 1.0, seed, cap, game_id_base=base, flags=abi.mcts_tune(0, 4, 2))
+    st = b.mcts_stats()
+    assert st.sims == G * sims and st.faults == 0 and st.rollouts + st.terminal_hits == st.sims
+    assert st.spec_issued > 0 and st.spec_hits > 0
+    kids, cnt = b.mcts_root_children(256)
+    p = TaflMctsParams(sims, cap, 1.0, seed, 0, 0)
+    for gid in (0, 63, 64, 1777, 4095, 4096, 8191):
+        assert _kids(kids, cnt, gid, 256) == _oracle_kids(lg, states[gid], wb, p, base + gid), gid
+    # the same search with one slot (no prediction at all) must agree game by game
+    b.mcts_run(sims, 1.0, seed, cap, game_id_base=base, flags=abi.mcts_tune(0, 1, 1))
+    k1, c1 = b.mcts_root_children(256)
+    for g in range(0, G, 37):
+        assert _kids(kids, cnt, g, 256) == _kids(k1, c1, g, 256), g
+
+
+def test_async_searches_equal_the_synchronous_one_and_the_oracle():
+    """tafl_mcts_run_async / _after / tafl_mcts_wait: two half-size batches searched side by side, the second half a search behind the first,
+    re-issued several times like a self-play loop - per game identical to one synchronous search of the whole id range and to the oracle."""
+    rules, fen, wb, n, lg = _mk("copenhagen11")
+    G, H, sims, cap, seed = 16384, 8192, 40, 160, 4
+    glg = gpu_logic(rules, n, wb)
+    whole = glg.new_batch(G, fen)
+    plies = (C.c_uint32 * G)(*[(i * 3) % 48 for i in range(G)])
+    whole.random_advance(1, plies, 0)
+    states = whole.download()
+    whole.mcts_run(sims, 1.0, seed, cap, game_id_base=0)
+    wk, wc = whole.mcts_root_children(64)
+    halves = [glg.new_batch(H), glg.new_batch(H)]
+    for i, hb in enumerate(halves):
+        hb.upload((TaflState * H).from_buffer_copy(bytes(states)[i * H * C.sizeof(TaflState):(i + 1) * H * C.sizeof(TaflState)]))
+    for rep in range(3):
+        halves[0].mcts_run_async(sims, 1.0, seed, cap, game_id_base=0)
+        halves[1].mcts_run_async(sims, 1.0, seed, cap, game_id_base=H, after=halves[0])
+        if rep == 1:                                     # re-issue the first while the second is still in flight
+            halves[0].mcts_wait()
+            halves[0].mcts_run_async(sims, 1.0, seed, cap, game_id_base=0)
+        for hb in halves:
+            hb.mcts_wait()
+    for i, hb in enumerate(halves):
+        st = hb.mcts_stats()
+        assert st.sims == H * sims and st.faults == 0
+        hk, hc = hb.mcts_root_children(64)              # (a reader joins a search in flight by itself; here it is already joined)
+        for g in range(0, H, 29):
+            assert _kids(hk, hc, g, 64) == _kids(wk, wc, i * H + g, 64), (i, g)
+    p = TaflMctsParams(sims, cap, 1.0, seed, 0, 0)
+    hk, hc = halves[1].mcts_root_children(64)
+    for g in (0, 77, 8191):
+        assert _kids(hk, hc, g, 64) == _oracle_kids(lg, states[H + g], wb, p, H + g), g
+    # a reader called without tafl_mcts_wait joins the search itself
+    halves[0].mcts_run_async(sims, 1.0, seed, cap, game_id_base=0)
+    k2, c2 = halves[0].mcts_root_children(64)
+    for g in range(0, H, 411):
+        assert _kids(k2, c2, g, 64) == _kids(wk, wc, g, 64), g
+    assert pu.states_equal(states, whole.download(), 64), "searches must not modify the batch"
+
+
+def test_full_size_13x13_properties_65536():
+    """BASELINE configs[4] at full size: 65 536 concurrent 13x13 games in the dense 13-column search layout - conservation properties,
+    shard invariance and oracle spot ids, as for the 11x11 headline."""
+    rules, fen, wb, n, lg = _mk("copenhagen13")
+    G, sims, cap, seed = 65536, 6, 96, 3
+    glg = gpu_logic(rules, n, wb)
+    big = glg.new_batch(G, fen)
+    big.mcts_run(sims, 1.0, seed, cap, game_id_base=0)
+    kids, cnt = big.mcts_root_children(16)
+    st = big.mcts_stats()
+    assert st.sims == G * sims and st.faults == 0
+    assert st.rollouts + st.terminal_hits == st.sims and sum(st.reason_hist) == st.rollouts
+    for g in range(0, G, 97):
+        assert sum(kids[g * 16 + j].visits for j in range(cnt[g])) == sims - 1
+    quarter = glg.new_batch(G // 4, fen)
+    quarter.mcts_run(sims, 1.0, seed, cap, game_id_base=3 * (G // 4))
+    qk, qc = quarter.mcts_root_children(16)
+    for g in range(0, G // 4, 53):
+        assert _kids(qk, qc, g, 16) == _kids(kids, cnt, 3 * (G // 4) + g, 16), g
+    p = TaflMctsParams(sims, cap, 1.0, seed, 0, 0)
+    one = pu.start_states(orc, fen, rules.starting_side, wb, 1)
+    for gid in (0, 65, 32767, 65535):
+        assert _kids(kids, cnt, gid, 16) == _oracle_kids(lg, one[0], wb, p, gid), gid
+    res = big.rollout(7, 0, 200, 0)
+    oneres = orc.batch_rollout(lg, one, 1, wb, 7, 0, 200, 4097)
+    assert (oneres[0].value, oneres[0].reason, oneres[0].plies) == (res[4097].value, res[4097].reason, res[4097].plies)
 
 
 def test_training_tensor_writers():

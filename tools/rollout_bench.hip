@@ -20,6 +20,9 @@ using namespace tafl;
 #ifndef LB
 #define LB 1
 #endif
+#ifndef EXTRA_GRID
+#define EXTRA_GRID 1
+#endif
 #ifdef TAFL_PROF
 // -DTAFL_PROF: per-section shader-clock totals of the playout loop (tafl_bits.hpp TAFL_PROF_*): where the cycles of one ply go
 extern "C" __device__ unsigned long long tafl_prof_acc[4096 * 32] = {};
@@ -31,7 +34,7 @@ template <int NL, int W, int PRESET>
 __global__ __launch_bounds__(64, LB) void k_roll(const Quad* soa, uint32_t n, uint64_t seed, uint32_t sim, uint32_t max_plies, uint64_t base,
                                                  tafl_rollout_result* out) {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    if (g >= n) return;
+    if (g >= n) return;                                  // (-DEXTRA_GRID=k launches k x the blocks needed: the surplus leaves here)
     constexpr Consts<NL> C = preset_consts<NL, W, PRESET>();
     DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
     tafl_rollout_result r;
@@ -60,7 +63,7 @@ int run(const char* board, uint32_t word_bits, uint32_t max_plies, int reps) {
         float best = 1e30f;
         for (int r = 0; r < reps + 1; ++r) {
             CK(hipEventRecord(a, 0));
-            hipLaunchKernelGGL((k_roll<NL, W, PRESET>), dim3(n / 64), dim3(64), 0, 0, soa, n, 3ull, 0u, max_plies, 0ull, out);
+            hipLaunchKernelGGL((k_roll<NL, W, PRESET>), dim3(n / 64 * EXTRA_GRID), dim3(64), 0, 0, soa, n, 3ull, 0u, max_plies, 0ull, out);
             CK(hipEventRecord(b, 0)); CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, a, b));
             if (r > 0 && ms < best) best = ms;
