@@ -72,6 +72,7 @@ SYMBOLS = [
     ("tafl_timing_enable", _i32, [_vp, _i32]),
     ("tafl_timing_reset", _i32, [_vp]),
     ("tafl_timing_get", _i32, [_vp, _i32, _P(_dbl), _P(_u64)]),
+    ("tafl_timing_get_union", _i32, [_vp, _i32, _P(_dbl), _P(_dbl)]),
     ("tafl_ctx_stream", _vp, [_vp]),
 ]
 

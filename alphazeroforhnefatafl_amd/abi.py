@@ -58,9 +58,9 @@ MCTS_FLAG_FPU_INF = 0x1          # src/mcts.rs:49-51,187: unvisited actions scor
 MCTS_PIPELINE_DEFAULT, MCTS_PIPELINE_FUSED, MCTS_PIPELINE_TWO_KERNEL = 0, 1, 2
 
 
-def mcts_tune(pipeline: int = 0, slots: int = 0, parts: int = 0) -> int:
-    """TAFL_MCTS_TUNE_PIPELINE(pipeline) | TAFL_MCTS_TUNE_SLOTS(slots) | TAFL_MCTS_TUNE_PARTS(parts)."""
-    return ((pipeline & 15) << 4) | ((slots & 15) << 8) | ((parts & 15) << 12)
+def mcts_tune(pipeline: int = 0, slots: int = 0, parts: int = 0, share: int = 0) -> int:
+    """TAFL_MCTS_TUNE_PIPELINE(pipeline) | TAFL_MCTS_TUNE_SLOTS(slots) | TAFL_MCTS_TUNE_PARTS(parts) | TAFL_MCTS_TUNE_SHARE(share)."""
+    return ((pipeline & 15) << 4) | ((slots & 15) << 8) | ((parts & 15) << 12) | ((share & 15) << 16)
 
 
 def ps_none() -> int:

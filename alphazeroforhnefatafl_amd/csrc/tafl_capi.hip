@@ -12,7 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "tafl_host.hpp"
@@ -518,6 +520,10 @@ struct tafl_ctx {
     bool timing;
     std::vector<TimedSpan> spans;
     double acc_ms[KC_COUNT]; uint64_t acc_n[KC_COUNT];
+    // the same spans as intervals on one clock (milliseconds since `t_ref`, recorded by tafl_timing_reset): launches of a class that
+    // overlap on different streams are counted once by tafl_timing_get_union
+    hipEvent_t t_ref; bool has_ref;
+    std::vector<std::pair<float, float>> ivals[KC_COUNT];
 };
 
 struct DevBuf {
@@ -632,7 +638,11 @@ static void drain_spans(tafl_ctx* c) {
     for (auto& s : c->spans) {
         (void)hipEventSynchronize(s.b);
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { c->acc_ms[s.cls] += ms; c->acc_n[s.cls] += 1; }
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->acc_ms[s.cls] += ms; c->acc_n[s.cls] += 1;
+            float t0 = 0.f;
+            if (c->has_ref && hipEventElapsedTime(&t0, c->t_ref, s.a) == hipSuccess) c->ivals[s.cls].push_back(std::make_pair(t0, t0 + ms));
+        }
         (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
     }
     c->spans.clear();
@@ -665,7 +675,7 @@ int tafl_ctx_create(const tafl_rules* rules, uint8_t side_len, uint32_t word_bit
     tafl_ctx* c = new (std::nothrow) tafl_ctx();
     if (!c) return fail(TAFL_ERR_OOM, "out of host memory");
     c->rules = *rules; c->n = side_len; c->word_bits = word_bits; c->nl = (uint32_t)l64 * 2; c->w = (uint32_t)rw; c->device = device;
-    c->timing = false; c->rollout_capacity = 0; c->live_batches = 0;
+    c->timing = false; c->rollout_capacity = 0; c->live_batches = 0; c->has_ref = false;
     c->preset = detect_preset(*rules, side_len, word_bits);
     for (int i = 0; i < KC_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
     int rc = 0;
@@ -685,6 +695,7 @@ int tafl_ctx_destroy(tafl_ctx* c) {
     if (c->live_batches != 0) return fail(TAFL_ERR_INVALID_ARG, "tafl_ctx_destroy: batches of this context are still alive (destroy them first)");
     (void)hipSetDevice(c->device);
     drain_spans(c);
+    if (c->has_ref) (void)hipEventDestroy(c->t_ref);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TAFL_OK;
@@ -740,7 +751,11 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
     tafl_batch* b = new (std::nothrow) tafl_batch();
     if (!b) return fail(TAFL_ERR_OOM, "out of host memory");
     b->ctx = c; b->n = n; b->has_mem = false; b->reserved_sims = 0; b->ran = false; b->soa = nullptr; b->g_has = false; b->g_max_sims = 0; b->trace_rounds = 0;
+#ifdef TAFL_EXPERIMENT_SPEC_K
+    b->spec_k = TAFL_EXPERIMENT_SPEC_K;      // measurement builds only
+#else
     b->spec_k = TAFL_MCTS_MAX_SLOTS;
+#endif
     b->n_sstreams = 0; b->half_recorded = false;
     memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats); memset(&b->plan, 0, sizeof b->plan);
     const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
@@ -1097,6 +1112,10 @@ static int mcts_begin(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id
             c->rollout_capacity = (uint32_t)blocks * (uint32_t)prop.multiProcessorCount * TAFL_BLOCK;
         }
         capacity = c->rollout_capacity;
+        // batches that are searched side by side (tafl_mcts_run_async) each take their share of the device: a round that fills its share
+        // EXACTLY keeps every SIMD at the same number of waves - a few workgroups more and some SIMDs carry one wave more than the others,
+        // and the whole round takes that wave's time (1 / 2 / 3 / 4 waves per SIMD: 1.0 / 1.5 / 2.0 / 2.55 ms per 512-ply round)
+        if (TAFL_MCTS_TUNE_SHARE_OF(p->flags) > 1) { capacity = capacity / TAFL_MCTS_TUNE_SHARE_OF(p->flags) / TAFL_BLOCK * TAFL_BLOCK; if (capacity < TAFL_BLOCK) capacity = TAFL_BLOCK; }
         if (slots == 0) {                                           // what fills the device exactly: 4 slots per game at 65 536 games on 11x11
             slots = capacity / n;
             if (slots < 1) slots = 1;
@@ -1572,7 +1591,30 @@ int tafl_timing_reset(tafl_ctx* c) {
     if (!c) return fail(TAFL_ERR_INVALID_ARG, "null ctx");
     (void)hipSetDevice(c->device);
     drain_spans(c);
-    for (int i = 0; i < KC_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; }
+    for (int i = 0; i < KC_COUNT; ++i) { c->acc_ms[i] = 0; c->acc_n[i] = 0; c->ivals[i].clear(); }
+    if (!c->has_ref) { if (hipEventCreate(&c->t_ref) != hipSuccess) return fail(TAFL_ERR_HIP, "hipEventCreate failed"); c->has_ref = true; }
+    HIPCHK(hipEventRecord(c->t_ref, c->stream));
+    HIPCHK(hipEventSynchronize(c->t_ref));
+    return TAFL_OK;
+}
+// wall-clock time during which AT LEAST ONE launch of the class was running (union of the spans' intervals), and the sum of the spans:
+// sum / union = how many launches of the class were in flight on average (partitions on their own streams overlap)
+int tafl_timing_get_union(tafl_ctx* c, int cls, double* union_ms, double* sum_ms) {
+    if (!c || cls < 0 || cls >= KC_COUNT) return fail(TAFL_ERR_INVALID_ARG, "bad kernel class");
+    (void)hipSetDevice(c->device);
+    drain_spans(c);
+    std::vector<std::pair<float, float>> v = c->ivals[cls];
+    std::sort(v.begin(), v.end());
+    double u = 0.0, s = 0.0; float lo = 0.f, hi = -1.f;
+    for (const auto& iv : v) {
+        s += (double)iv.second - (double)iv.first;
+        if (hi < lo) { lo = iv.first; hi = iv.second; }
+        else if (iv.first <= hi) { if (iv.second > hi) hi = iv.second; }
+        else { u += (double)hi - (double)lo; lo = iv.first; hi = iv.second; }
+    }
+    if (hi >= lo) u += (double)hi - (double)lo;
+    if (union_ms) *union_ms = u;
+    if (sum_ms) *sum_ms = s;
     return TAFL_OK;
 }
 int tafl_timing_get(tafl_ctx* c, int cls, double* total_ms, uint64_t* launches) {

@@ -84,6 +84,12 @@ class BatchedGameLogic:
         check(lib().tafl_timing_get(self._h, kernel_class, C.byref(ms), C.byref(k)))
         return ms.value, k.value
 
+    def timing_get_union(self, kernel_class: int):
+        """(time with at least one launch of the class in flight, sum of the launch durations) in ms since the last reset."""
+        u, t = C.c_double(), C.c_double()
+        check(lib().tafl_timing_get_union(self._h, kernel_class, C.byref(u), C.byref(t)))
+        return u.value, t.value
+
 
 class GameBatch:
     """n GameState<T> values in HBM + the batched GameLogic operations over them."""

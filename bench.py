@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 GAMES_PER_GPU = 65536
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2   # wave64 VALU instructions per second: 1 024 SIMD-32 x 2.4 GHz, 2 cycles per instruction (MI355X_MICROARCH.md "Wave scheduling")
 SG_BYTES = {7: 48, 11: 64, 13: 96}   # SoA state bytes per game (SURVEY.md section 8d S_g)
 BOARDS = {"copenhagen11": ("COPENHAGEN", "COPENHAGEN", 11, 128), "copenhagen13": ("COPENHAGEN", "COPENHAGEN13", 13, 256),
           "brandubh7": ("BRANDUBH", "BRANDUBH", 7, 64)}
@@ -205,7 +206,8 @@ def timed_mcts(logic, batch, sims, cpuct, seed, cap, base, steps, warmup, sync, 
     sync()
     elapsed = time.perf_counter() - t0
     logic.timing_enable(False)
-    kt = {"rollout": logic.timing_get(KC_MCTS_ROLLOUT), "tree": logic.timing_get(KC_MCTS_TREE)}
+    kt = {"rollout": logic.timing_get(KC_MCTS_ROLLOUT), "tree": logic.timing_get(KC_MCTS_TREE),
+          "rollout_union": logic.timing_get_union(KC_MCTS_ROLLOUT), "tree_union": logic.timing_get_union(KC_MCTS_TREE)}
     return elapsed, batch.mcts_stats(), kt
 
 
@@ -220,11 +222,15 @@ def mcts_roofline(stats, kt, steps, side, traffic=None, traffic_source=None):
     fused = tree_n == 0
     kname = "k_mcts_fused" if fused else "k_mcts_rollout"
     alg = bps * float(stats.sims) + (sg + 4) * max(0, executed - int(stats.rollouts)) if fused else float((sg + 4) * executed)
-    s_per_step = roll_ms * 1e-3 / steps
+    # the partitions' launches overlap on their streams: the kernel's time is the UNION of the launch intervals (live HIP events on the
+    # streams the kernel runs on), launch_avg_ms the plain average of the launch durations, overlap_factor = sum / union
+    union_ms, sum_ms = kt.get("rollout_union", (roll_ms, roll_ms))
+    s_per_step = union_ms * 1e-3 / steps
     achieved = alg / s_per_step / 1e9 if s_per_step > 0 else 0.0
     r = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": traffic, "algorithmic_bytes": alg, "kernel_ms": s_per_step * 1e3, "per": "step (all %s launches)" % kname,
-         "launch_avg_ms": roll_ms / max(roll_n, 1), "launches_per_step": roll_n / steps, "playouts_executed": executed}
+         "traffic": traffic, "algorithmic_bytes": alg, "kernel_ms": s_per_step * 1e3, "per": "step (union of the %s launch intervals)" % kname,
+         "launch_avg_ms": roll_ms / max(roll_n, 1), "launches_per_step": roll_n / steps, "overlap_factor": sum_ms / union_ms if union_ms > 0 else 0.0,
+         "playouts_executed": executed}
     if traffic is not None:
         r["traffic_source"] = traffic_source
     return r, kname, bps, d_bar, c_bar
@@ -302,22 +308,60 @@ def run_variants(args, torch):
     def sync():
         torch.cuda.synchronize()
 
-    def mcts_variant(board, sims, steps, warmup):
+    def mcts_variant(board, sims, steps, warmup, mixed=False):
         rn, bn, side, wb = BOARDS[board]
         logic = BatchedGameLogic(getattr(abi.rules, rn), side, wb, device=0)
         batch = logic.new_batch(GAMES_PER_GPU, getattr(abi.boards, bn))
+        if mixed:       # the configs[1] input recipe: game i advanced by (i mod 64) seeded random plies - what self-play batches look like
+            batch.random_advance(1, (C.c_uint32 * GAMES_PER_GPU)(*[i % 64 for i in range(GAMES_PER_GPU)]), 0)
         batch.mcts_reserve(sims)
         el, st, kt = timed_mcts(logic, batch, sims, args.cpuct, args.seed, args.max_plies, 0, steps, warmup, sync)
         roof, kname, bps, d_bar, c_bar = mcts_roofline(st, kt, steps, side)
         assert st.sims == GAMES_PER_GPU * sims and st.faults == 0, (board, sims, st.sims, st.faults)
-        r = {"workload": f"{GAMES_PER_GPU} x {side}x{side} {board}, S={sims}, cap {args.max_plies}", "value": GAMES_PER_GPU * sims * steps / el,
+        r = {"workload": f"{GAMES_PER_GPU} x {side}x{side} {board}, S={sims}, cap {args.max_plies}" + (", positions after (i mod 64) random plies" if mixed else ", start position"),
+             "value": GAMES_PER_GPU * sims * steps / el,
              "unit": "sims/s", "ms_per_step": el / steps * 1e3, "env_steps_per_sec": float(st.rollout_plies) * steps / el,
              "mean_select_depth": d_bar, "mean_children_scanned": c_bar, "spec_hit_rate": st.spec_hits / max(st.spec_issued, 1),
+             "plies_per_rollout": float(st.rollout_plies) / max(st.rollouts, 1), "capped_rollout_frac": st.reason_hist[14] / max(st.rollouts, 1),
              "algorithmic_bytes_per_sim": bps, "roofline": roof}
         batch.close()
         logic.close()
         return r
 
+    def guided_variant(sims=64):
+        """Guided mode (the caller's network as nnet.predict) with a FREE evaluator: constant float32 priors and zero values resident in HBM,
+        so that only the library's share of a round is timed (k_gmcts_step + k_gmcts_leaves); 65 536 games, device pointers."""
+        from alphazeroforhnefatafl_amd import GuidedMCTS, MCTSArgs
+        dev = torch.device("cuda:0")
+        n, side = GAMES_PER_GPU, 11
+        lg = BatchedGameLogic(abi.rules.COPENHAGEN, side, 128, device=0)
+        A = lg.action_size
+        bt = torch.zeros((n, side, side), dtype=torch.uint8, device=dev); stt = torch.zeros(n, dtype=torch.uint8, device=dev); wt = torch.zeros(n, dtype=torch.uint8, device=dev)
+        pri = torch.rand((n, A), dtype=torch.float32, device=dev); val = torch.zeros(n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+
+        class Const:
+            def predict_batch(self, *_):
+                return pri.data_ptr(), val.data_ptr()
+        b = lg.new_batch(n, abi.boards.COPENHAGEN)
+        m = GuidedMCTS(b, Const(), MCTSArgs(numMCTSSims=sims, cpuct=1.0), edges_per_node=192, device=True, buffers=(bt.data_ptr(), stt.data_ptr(), wt.data_ptr()))
+        m.search_all()                                           # first search allocates the arena
+        b.reset_fen(abi.boards.COPENHAGEN, abi.rules.COPENHAGEN.starting_side)
+        m.rounds = 0
+        lg.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.search_all()
+        lg.sync(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gs = b.gmcts_stats()
+        r = {"workload": f"{n} x 11x11 guided MCTS (external evaluator), S={sims}, free evaluator (constant priors in HBM)", "value": gs.sims / dt, "unit": "sims/s",
+             "rounds": m.rounds, "ms_per_round": 1e3 * dt / max(1, m.rounds), "predicts": int(gs.predicts), "faults": int(gs.faults)}
+        b.close(); lg.close()
+        del bt, stt, wt, pri, val
+        torch.cuda.empty_cache()
+        return r
+
+    out["mcts_mixed_positions_S64"] = mcts_variant("copenhagen11", 64, 3, 1, mixed=True)
     out["mcts_S256"] = mcts_variant("copenhagen11", 256, 2, 1)
     out["mcts_S1000"] = mcts_variant("copenhagen11", 1000, 1, 1)
     out["mcts_13x13_S64"] = mcts_variant("copenhagen13", 64, 3, 1)
@@ -328,7 +372,36 @@ def run_variants(args, torch):
         for G in (4096, 65536):
             out[f"streamed_{board}_{G}"] = streamed_variant(logic, getattr(abi.boards, bn), side, G)
         logic.close()
+    out["guided_engine_only_S64"] = guided_variant(64)
     return out
+
+
+def make_digest(out):
+    """<= 1 500 characters of the numbers a reader wants first, put LAST in the JSON line (a log tail keeps them)."""
+    v = out.get("variants", {})
+
+    def m(key):
+        x = v.get(key)
+        return "-" if not x else "%.1fM(hit %.2f)" % (x["value"] / 1e6, x.get("spec_hit_rate", 0.0))
+
+    def st(key, k):
+        x = v.get(key, {}).get(k)
+        return "-" if not x else "%.1f" % x["us"]
+    roof = out["roofline"]
+    parts = ["S64 %.1fM sims/s %.1fms/step %.1fG plies/s" % (out["value"] / 1e6, out["ms_per_step"], out["env_steps_per_sec"] / 1e9),
+             "hit %.2f" % (out["mcts"]["spec_hits"] / max(out["mcts"]["spec_issued"], 1)),
+             "rollout launch %.2fms x%.0f/step union %.1fms overlap %.2f" % (roof["launch_avg_ms"], roof["launches_per_step"], roof["kernel_ms"], roof["overlap_factor"]),
+             "tree %.3fms" % out["kernels_ms"]["k_mcts_tree"]["avg"],
+             "mixed-positions S64 " + m("mcts_mixed_positions_S64"), "S256 " + m("mcts_S256"), "S1000 " + m("mcts_S1000"), "13x13 " + m("mcts_13x13_S64"),
+             "brandubh7 " + m("mcts_brandubh7_S64"),
+             "guided(free evaluator) %s" % ("-" if "guided_engine_only_S64" not in v else "%.1fM" % (v["guided_engine_only_S64"]["value"] / 1e6)),
+             "streamed us @65536 11x11: counts %s masks %s step %s step_kth %s rollout %s" % tuple(st("streamed_copenhagen11_65536", k) for k in ("movegen_counts", "movegen_masks", "step", "step_kth", "rollout")),
+             "@4096: masks %s step %s step_kth %s" % tuple(st("streamed_copenhagen11_4096", k) for k in ("movegen_masks", "step", "step_kth")),
+             "13x13 @65536: masks %s step %s step_kth %s" % tuple(st("streamed_copenhagen13_65536", k) for k in ("movegen_masks", "step", "step_kth"))]
+    cb = out.get("cpu_baseline")
+    if cb:
+        parts.append("cpu oracle %.0f sims/s x1 thread, %.0f x%d" % (cb["value"], cb["all_cores"]["value"], cb["all_cores"]["cores"]))
+    return "; ".join(parts)[:1500]
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -349,14 +422,16 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0, help="tuning: MCTS pipeline (0 default, 1 fused kernel, 2 two-kernel); results do not depend on it")
     ap.add_argument("--slots", type=int, default=0, help="tuning: playout slots per game the search is planned for (0 = from the batch size)")
     ap.add_argument("--parts", type=int, default=0, help="tuning: partitions of the batch on their own streams (0 = from the batch size)")
-    ap.add_argument("--backend", default=None, help="torch.distributed backend for the barrier / reductions (default nccl = RCCL; gloo with --single-device)")
+    ap.add_argument("--backend", default=None, choices=["auto", "nccl", "gloo"],
+                    help="collective library for the timing barrier (the data path has no collective): auto = RCCL if it comes up on every rank, "
+                         "else gloo (default); nccl = RCCL or exit non-zero; gloo (default with --single-device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0 (barrier over gloo)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: every rank joins the gloo group, "
                     "reports its device and game-id shard, rank 0 prints the table; no engine call is made")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    backend = args.backend or ("gloo" if args.single_device else "nccl")
+    backend = args.backend or ("gloo" if args.single_device else "auto")
 
     has_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not has_env:
@@ -392,8 +467,8 @@ def main():
     elif local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: GPU {local_rank} does not exist ({torch.cuda.device_count()} visible); use --single-device to rehearse on one GPU")
     torch.cuda.set_device(local_rank)
-    tdist.init(backend, rank, world)    # RCCL: only for the barrier and the reductions of the elapsed time / counters
-    red_dev = "cuda" if backend == "nccl" else "cpu"
+    tdist.init(backend, rank, world)    # RCCL: only for the barrier; the reductions of the elapsed time / counters are host scalars over gloo
+    red_dev = "cpu"
 
     from alphazeroforhnefatafl_amd import abi
     from alphazeroforhnefatafl_amd.engine import BatchedGameLogic
@@ -447,6 +522,7 @@ def main():
                        "games_per_gpu": G, "games_total": G * world, "sims_per_root": args.sims, "max_rollout_plies": args.max_plies,
                        "c_puct": args.cpuct, "seed": args.seed, "pipeline": args.pipeline, "slots": args.slots, "sharding": f"game-id ranges x{world}, no collectives",
                        "launcher": "bench.py child processes" if os.environ.get("TAFL_BENCH_CHILD") else ("torch.distributed.run" if has_env else "single process"),
+                       "barrier_backend": tdist.backend_in_use()[0], "barrier_note": tdist.backend_in_use()[1],
                        "single_device_rehearsal": bool(args.single_device)},
             "per_rank_sims_per_sec": [G * args.sims * args.steps / t for t in per_rank],
             "env_steps_per_sec": total_plies / elapsed,
@@ -460,11 +536,23 @@ def main():
                            "k_mcts_tree": {"avg": tree_ms / max(tree_n, 1), "launches": int(tree_n), "total_per_step": tree_ms / args.steps}},
             "roofline": roof,
         }
+        # the honest ceiling of this path is VALU issue, not HBM: wave64 VALU instructions per step from the committed SQ counter pass
+        # of this command (profiles/, like `traffic`), over this run's measured step time
+        ppath = os.path.join(ROOT, "profiles", "valu_k_mcts_rollout.json")
+        if headline and os.path.exists(ppath):
+            with open(ppath) as f:
+                pj = json.load(f)
+            insts = float(pj.get("valu_wave_instructions_per_step", 0.0))
+            if insts > 0:
+                ach = insts / (elapsed / args.steps)
+                out["roofline_valu"] = {"bound": "valu_issue", "achieved": ach, "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instructions/s", "frac": ach / VALU_ISSUE_PEAK,
+                                        "instructions_per_step": insts, "source": "profiles/valu_k_mcts_rollout.json: " + pj.get("source", "")}
         batch.close()
         if world == 1 and not args.no_variants and headline:
             out["variants"] = run_variants(args, torch)
         if world == 1 and not args.no_cpu_baseline and args.board == "copenhagen11":
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpuct, args.seed, args.max_plies)
+        out["digest"] = make_digest(out)                     # last key on purpose
         print(json.dumps(out), flush=True)
     if world > 1:
         tdist.barrier(world)

@@ -218,9 +218,11 @@ typedef struct tafl_mcts_params {
 #define TAFL_MCTS_TUNE_SLOTS(x) (((uint32_t)(x) & 15u) << 8)
 #define TAFL_MCTS_TUNE_PARTS(x) (((uint32_t)(x) & 15u) << 12)
 #define TAFL_MCTS_TUNE_PARTS_OF(f) (((f) >> 12) & 15u)
+#define TAFL_MCTS_TUNE_SHARE(x) (((uint32_t)(x) & 15u) << 16)     /* this search may fill 1/x of the device (0 = all of it): batches searched side by side */
+#define TAFL_MCTS_TUNE_SHARE_OF(f) (((f) >> 16) & 15u)
 #define TAFL_MCTS_TUNE_PIPELINE_OF(f) (((f) >> 4) & 15u)
 #define TAFL_MCTS_TUNE_SLOTS_OF(f) (((f) >> 8) & 15u)
-#define TAFL_MCTS_FLAGS_KNOWN 0x0000FFF1u
+#define TAFL_MCTS_FLAGS_KNOWN 0x000FFFF1u
 
 typedef struct tafl_mcts_stats {
     uint64_t sims;             /* simulations executed (all games) */
@@ -416,6 +418,8 @@ int tafl_mcts_round_trace(tafl_batch* b, uint32_t* requested, uint32_t* run, uin
 int tafl_timing_enable(tafl_ctx* ctx, int enable);
 int tafl_timing_reset(tafl_ctx* ctx);
 int tafl_timing_get(tafl_ctx* ctx, int kernel_class, double* total_ms, uint64_t* launches);
+int tafl_timing_get_union(tafl_ctx* ctx, int kernel_class, double* union_ms, double* sum_ms);   /* time with >= 1 launch of the class
+    in flight (launches on different streams overlap) and the plain sum of the launch durations, since the last reset */
 void* tafl_ctx_stream(tafl_ctx* ctx);
 
 #ifdef __cplusplus

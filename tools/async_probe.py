@@ -5,7 +5,9 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from alphazeroforhnefatafl_amd import abi
+from alphazeroforhnefatafl_amd import abi, _lib
+if os.environ.get('PROBE_LIB'):
+    _lib.LIB_PATH = os.environ['PROBE_LIB']          # measurement only: A/B another build of the library
 from alphazeroforhnefatafl_amd.engine import BatchedGameLogic
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -28,10 +30,10 @@ def sync_mode(parts, slots):
     return {"mode": "sync", "parts": parts, "slots": slots, "sims_per_s": G * S * STEPS / dt, "ms_per_step": dt / STEPS * 1e3, "hit": st.spec_hits / max(st.spec_issued, 1)}
 
 
-def async_mode(nb, parts, slots):
-    H = G // nb
+def async_mode(nb, parts, slots, share=0):
+    H = G // nb // 64 * 64
     bs = [logic.new_batch(H, abi.boards.COPENHAGEN) for _ in range(nb)]
-    fl = abi.mcts_tune(0, slots, parts)
+    fl = abi.mcts_tune(0, slots, parts, share)
 
     def go(steps):
         for i, b in enumerate(bs):
@@ -51,7 +53,7 @@ def async_mode(nb, parts, slots):
         st = b.mcts_stats(); assert st.sims == H * S and st.faults == 0; hit += st.spec_hits / max(st.spec_issued, 1) / nb
     for b in bs:
         b.close()
-    return {"mode": "async x%d" % nb, "parts": parts, "slots": slots, "sims_per_s": G * S * STEPS / dt, "ms_per_step": dt / STEPS * 1e3, "hit": hit}
+    return {"mode": "async x%d" % nb, "parts": parts, "slots": slots, "share": share, "sims_per_s": H * nb * S * STEPS / dt, "ms_per_step": dt / STEPS * 1e3, "hit": hit}
 
 
 MODES = sys.argv[3].split(",") if len(sys.argv) > 3 else ["sync", "async"]
@@ -71,7 +73,11 @@ if "sync" in MODES:
     for parts, slots in ((2, 0), (2, 4)):
         print(json.dumps(sync_mode(parts, slots)), flush=True)
 if "async" in MODES:
-    for nb, parts, slots in ((2, 1, 4), (2, 1, 5)):
-        print(json.dumps(async_mode(nb, parts, slots)), flush=True)
+    for nb, parts, slots, share in ((2, 1, 4, 0), (2, 1, 4, 2), (2, 1, 0, 2), (2, 1, 5, 2)):
+        print(json.dumps(async_mode(nb, parts, slots, share)), flush=True)
+if "async4" in MODES:
+    for nb, parts, slots, share in ((4, 1, 4, 4), (4, 1, 0, 4), (3, 1, 4, 3), (2, 2, 4, 2)):
+        if G % nb == 0 or nb == 3:
+            print(json.dumps(async_mode(nb, parts, slots, share)), flush=True)
 if "async1" in MODES:
     print(json.dumps(async_mode(2, 1, 4)), flush=True)

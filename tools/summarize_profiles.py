@@ -35,6 +35,7 @@ def main():
         ap.add_argument("--" + a, required=True)
     ap.add_argument("--algorithmic-bytes", type=float, default=None, help="algorithmic HBM bytes per step of k_mcts_rollout (bench.py roofline.algorithmic_bytes)")
     ap.add_argument("--traffic-json", default=None, help="also write the per-step traffic file bench.py reads")
+    ap.add_argument("--valu-json", default=None, help="also write the per-step VALU instruction count bench.py reads (roofline_valu)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     shutil.copy(newest(a.kt, "*kernel_stats.csv"), os.path.join(a.out, "kernel_stats.csv"))
@@ -48,9 +49,11 @@ def main():
                   "hbm_bytes_per_step_corrected": (2.0 * f_kb + w_kb) * 1024.0, "sq_per_step": {c: int(v) for c, v in sorted(sq[k].items())}}
         s = out[k]["sq_per_step"]
         if s.get("GRBM_GUI_ACTIVE") and s.get("SQ_INSTS_VALU"):
-            # GRBM_GUI_ACTIVE counts on 8 XCDs: /8 = busy shader-clock cycles of the kernel; peak = 1 VALU wave-instruction per 4 cycles per SIMD
+            # GRBM_GUI_ACTIVE counts on 8 XCDs: /8 = busy shader-clock cycles of the kernel; peak = 1 wave64 VALU instruction per 2 cycles per
+            # SIMD-32 (MI355X_MICROARCH.md "Wave scheduling"), 1 024 SIMDs.  (Launches of the two partitions overlap, so the busy cycles of a
+            # kernel are counted once per launch: this per-kernel figure is a lower bound; bench.py's roofline_valu uses the step's wall time.)
             cyc = s["GRBM_GUI_ACTIVE"] / 8.0
-            out[k]["valu_issue_fraction_of_peak"] = s["SQ_INSTS_VALU"] / (cyc * 1024 / 4.0)
+            out[k]["valu_issue_fraction_of_2cycle_peak_while_resident"] = s["SQ_INSTS_VALU"] / (cyc * 1024 / 2.0)
     json.dump(out, open(os.path.join(a.out, "pmc_summary.json"), "w"), indent=1)
     if a.traffic_json:
         k = next(k for k in out if "k_mcts_rollout" in k)
@@ -60,8 +63,15 @@ def main():
                    "correction": "gfx950 FETCH_SIZE reports 1/2 of wide (16 B/lane) coalesced reads: doubled (MI355X_MICROARCH.md, HBM)",
                    "hbm_bytes_per_step": out[k]["hbm_bytes_per_step_corrected"], "algorithmic_bytes_per_step": a.algorithmic_bytes},
                   open(a.traffic_json, "w"), indent=1)
+    if a.valu_json:
+        tot = sum(v["sq_per_step"].get("SQ_INSTS_VALU", 0) for v in out.values())
+        k = next(k for k in out if "k_mcts_rollout" in k)
+        json.dump({"config": "bench.py defaults (65536 games, 11x11 Copenhagen, S=64, two-kernel pipeline), ONE step",
+                   "source": os.path.join(a.out, "pmc_summary.json") + " (rocprofv3 --pmc SQ_INSTS_VALU ..., its own pass, one bench step)",
+                   "valu_wave_instructions_per_step": tot, "of_which_k_mcts_rollout": out[k]["sq_per_step"].get("SQ_INSTS_VALU", 0),
+                   "peak": "1 024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction = 1.2288e12 / s"}, open(a.valu_json, "w"), indent=1)
     for k, v in out.items():
-        print(k, {x: v[x] for x in ("dispatches_per_step", "hbm_bytes_per_step_corrected", "valu_issue_fraction_of_peak") if x in v})
+        print(k, {x: v[x] for x in ("dispatches_per_step", "hbm_bytes_per_step_corrected", "valu_issue_fraction_of_2cycle_peak_while_resident") if x in v})
 
 
 if __name__ == "__main__":
