@@ -67,38 +67,29 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_movegen(Consts<NL> C, const Quad
     counts[g] = Ops<NL, W>::movegen(st, C, nullptr);
 }
 
-// counts + dense action masks.  A workgroup of four waves serves 64 games: lane = game, WAVE = move direction (V+, V-, H+, H-), each
-// wave generating only its own direction's reach set and writing one bit field per piece (Ops::movegen_fields), so the direction is
-// wave-uniform (no divergence) and the work of a position is spread over four waves.  The masks are assembled in LDS (ds_or, odd row
-// stride: no bank conflicts) and streamed out as one contiguous block per workgroup (64 x mask_words uint32, fully coalesced).
-#define TAFL_MG_WAVES 4
+// counts + dense action masks.  A workgroup serves 64 games with ONE WAVE PER BOARD LINE (lane = game, wave i = row i and column i:
+// Ops::movegen_line), so the line index is wave-uniform (every bit position a scalar, no divergence between the lines) and the state loads
+// stay coalesced (quad-plane SoA: 1 KiB per wave instruction; the waves of a workgroup read the same 4 KiB, from L2 after the first).
+// The masks are assembled in LDS (ds_or, odd row stride: no bank conflicts) and streamed out as one contiguous block per workgroup
+// (64 x mask_words uint32, fully coalesced).
 template <int NL, int W>
-__device__ __forceinline__ uint32_t movegen_wave(const DState<NL>& st, uint32_t dir, const Consts<NL>& C, uint32_t* row) {      // dir is wave-uniform
-    switch (dir) {
-        case 0: return Ops<NL, W>::template movegen_fields<DIR_VP>(st, C, row);
-        case 1: return Ops<NL, W>::template movegen_fields<DIR_VM>(st, C, row);
-        case 2: return Ops<NL, W>::template movegen_fields<DIR_HP>(st, C, row);
-        default: return Ops<NL, W>::template movegen_fields<DIR_HM>(st, C, row);
-    }
-}
-template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK * TAFL_MG_WAVES) void k_movegen_masks(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t* counts, uint32_t* masks, uint32_t mw) {
+__global__ __launch_bounds__(TAFL_BLOCK * 15) void k_movegen_masks(Consts<NL> C, const Quad* soa, uint32_t n, uint32_t* counts, uint32_t* masks, uint32_t mw) {
     extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw | 1] masks, then [TAFL_BLOCK] counts
-    const uint32_t ldw = mw | 1u, lane = threadIdx.x & 63u, dir = threadIdx.x >> 6;
+    const uint32_t ldw = mw | 1u, lane = threadIdx.x & 63u, line = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lines = blockDim.x >> 6;     // lines == C.n
     const uint32_t g0 = blockIdx.x * TAFL_BLOCK, g = g0 + lane;
     uint32_t* lds_cnt = lds_masks + TAFL_BLOCK * ldw;
-    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * (ldw + 1u); i += TAFL_BLOCK * TAFL_MG_WAVES) lds_masks[i] = 0;
+    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * (ldw + 1u); i += blockDim.x) lds_masks[i] = 0;
     __syncthreads();
     if (g < n) {
         DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
-        const uint32_t c = movegen_wave<NL, W>(st, dir, C, lds_masks + (size_t)lane * ldw);
+        const uint32_t c = Ops<NL, W>::movegen_line(st, line, C, lds_masks + (size_t)lane * ldw);
         if (c) atomicAdd(&lds_cnt[lane], c);
     }
     __syncthreads();
-    if (dir == 0 && g < n && counts) counts[g] = lds_cnt[lane];
+    if (line == 0 && g < n && counts) counts[g] = lds_cnt[lane];
     const uint32_t games = (n - g0) < TAFL_BLOCK ? (n - g0) : TAFL_BLOCK;
     uint32_t* dst = masks + (size_t)g0 * mw;
-    for (uint32_t gi = dir; gi < games; gi += TAFL_MG_WAVES)                                  // one game per wave and pass: 304 contiguous bytes
+    for (uint32_t gi = line; gi < games; gi += lines)                                        // one game per wave and pass: 304 contiguous bytes
         for (uint32_t w = lane; w < mw; w += TAFL_BLOCK) dst[(size_t)gi * mw + w] = lds_masks[(size_t)gi * ldw + w];
 }
 
@@ -121,26 +112,99 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_step(Consts<NL> C, Quad* soa, ui
     if (eff) eff[g] = e;
 }
 
-// game i plays its (rank mod count)-th legal play in canonical order: the dense legal mask is built in LDS by four direction waves as in
-// k_movegen_masks, then the first wave (lane = game) finds the k-th set bit and applies the play
+// game i plays its (rank mod count)-th legal play in canonical order, in two launches:
+//   k_select_kth  the dense legal mask is built in LDS by one wave per board line as in k_movegen_masks; every wave then counts the plays in
+//                 its share of the mask words, and the first wave (lane = game) walks the partial counts to the chunk that holds the k-th
+//                 set bit and finds it there: the chosen dense action index per game (4 B) and the number of plays
+//   k_step_action do_valid_play of that action, one game per lane (k_step without the validation): a workgroup of one wave per 64 games,
+//                 so that as many games are being applied at once as the device has SIMDs (inside the line-wave workgroup only one wave in
+//                 eleven would do this, the longest dependent chain of the call)
+// The streamed step of a 256-bit batch whose board has at most 13 columns: the play is validated on the reference's 15-column words (the
+// error code of an off-board play depends on that layout, Engine::validate) and applied in the dense 13-column layout of the 13x13 search
+// (restride, tafl_core.hpp): six limbs instead of eight keep do_valid_play in registers (k_step<8, 15> carried 720 B of scratch per lane).
+template <bool VALIDATE>
+__device__ __forceinline__ void step_dense13(const Consts<8>& C, const Consts<6>& Cd, DState<8>& st, tafl_play play, uint32_t action, uint32_t total, tafl_play& pl, tafl_effects& e) {
+    using O8 = Ops<8, 15>; using E6 = Engine<6, 13>;
+    O8::caps_to_effects(bz<8>(), 0, e);
+    pl.from_row = pl.from_col = pl.axis = 0; pl.disp = 0;
+    Move m; m.from = m.to = m.dir = m.dist = 0;
+    int code;
+    if constexpr (VALIDATE) code = Engine<8, 15>::validate(st, play, st.flags & TAFL_F_SIDE, C, &m);
+    else {
+        if (total == 0) code = TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING ? TAFL_PLAY_GAME_OVER : TAFL_PLAY_NO_PIECE;
+        else if (action != O8::NO_ACTION) { m = O8::move_of_action(action, C); pl = O8::to_play(m); code = TAFL_PLAY_OK; }
+        else code = TAFL_PLAY_NO_PIECE;
+    }
+    if (code == TAFL_PLAY_OK) {
+        DState<6> d; restride<8, 15, 6, 13>(st, C.n, d);
+        Move md = m; md.from = restride_sq<15, 13>(m.from); md.to = restride_sq<15, 13>(m.to);
+        StepOut<6> so; Moves<6> nx;
+        E6::apply(d, md, Cd, &so, nx);
+        restride<6, 13, 8, 15>(d, C.n, st);
+        Bits<8> caps = bz<8>(); restride_rows<6, 13, 8, 15>(so.captures, C.n, caps);
+        O8::caps_to_effects(caps, so.n_captures, e);
+    }
+    O8::status_to_effects(st, code, e);
+}
+__global__ __launch_bounds__(TAFL_BLOCK) void k_step_dense13(Consts<8> C, Consts<6> Cd, Quad* soa, uint32_t n, const tafl_play* plays, tafl_effects* eff) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<8> st; StateIO<8>::load_soa(soa, n, g, st);
+    tafl_effects e; tafl_play pl;
+    step_dense13<true>(C, Cd, st, plays[g], 0u, 0u, pl, e);
+    StateIO<8>::store_soa(soa, n, g, st);
+    if (eff) eff[g] = e;
+}
+__global__ __launch_bounds__(TAFL_BLOCK) void k_step_action_dense13(Consts<8> C, Consts<6> Cd, Quad* soa, uint32_t n, const uint32_t* actions, const uint32_t* totals, tafl_play* out_plays, tafl_effects* eff) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<8> st; StateIO<8>::load_soa(soa, n, g, st);
+    tafl_effects e; tafl_play pl; tafl_play none; none.from_row = none.from_col = none.axis = 0; none.disp = 0;
+    step_dense13<false>(C, Cd, st, none, actions[g], totals[g], pl, e);
+    StateIO<8>::store_soa(soa, n, g, st);
+    if (eff) eff[g] = e;
+    if (out_plays) out_plays[g] = pl;
+}
+
 template <int NL, int W>
-__global__ __launch_bounds__(TAFL_BLOCK * TAFL_MG_WAVES) void k_step_kth(Consts<NL> C, Quad* soa, uint32_t n, const uint32_t* ranks, tafl_play* out_plays, tafl_effects* eff, uint32_t mw) {
-    extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw | 1] masks, then [TAFL_BLOCK] counts
-    const uint32_t ldw = mw | 1u, lane = threadIdx.x & 63u, dir = threadIdx.x >> 6;
+__global__ __launch_bounds__(TAFL_BLOCK * 15) void k_select_kth(Consts<NL> C, const Quad* soa, uint32_t n, const uint32_t* ranks, uint32_t* actions, uint32_t* totals, uint32_t mw) {
+    extern __shared__ uint32_t lds_masks[];                      // [TAFL_BLOCK][mw | 1] masks, [TAFL_BLOCK] counts, [TAFL_BLOCK][16] partial counts
+    const uint32_t ldw = mw | 1u, lane = threadIdx.x & 63u, line = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lines = blockDim.x >> 6;
     const uint32_t g = blockIdx.x * TAFL_BLOCK + lane;
     uint32_t* lds_cnt = lds_masks + TAFL_BLOCK * ldw;
-    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * (ldw + 1u); i += TAFL_BLOCK * TAFL_MG_WAVES) lds_masks[i] = 0;
+    uint32_t* lds_part = lds_cnt + TAFL_BLOCK;                    // [lane * 17 + line]
+    for (uint32_t i = threadIdx.x; i < TAFL_BLOCK * (ldw + 1u); i += blockDim.x) lds_masks[i] = 0;
     __syncthreads();
-    DState<NL> st;
     if (g < n) {
-        StateIO<NL>::load_soa(soa, n, g, st);
-        const uint32_t c = movegen_wave<NL, W>(st, dir, C, lds_masks + (size_t)lane * ldw);
+        DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
+        const uint32_t c = Ops<NL, W>::movegen_line(st, line, C, lds_masks + (size_t)lane * ldw);
         if (c) atomicAdd(&lds_cnt[lane], c);
     }
     __syncthreads();
-    if (dir != 0 || g >= n) return;
+    const uint32_t chunk = (mw + lines - 1u) / lines, w0 = line * chunk, w1 = (w0 + chunk) < mw ? (w0 + chunk) : mw;
+    {
+        uint32_t pc = 0;
+        for (uint32_t w = w0; w < w1; ++w) pc += (uint32_t)__builtin_popcount(lds_masks[(size_t)lane * ldw + w]);
+        lds_part[lane * 17u + line] = pc;
+    }
+    __syncthreads();
+    if (line != 0 || g >= n) return;
+    const uint32_t total = lds_cnt[lane];
+    uint32_t action = Ops<NL, W>::NO_ACTION;
+    if (total) {
+        uint32_t k = ranks[g] % total, j = 0; bool found = false;
+        for (uint32_t q = 0; q < lines; ++q) { const uint32_t pc = lds_part[lane * 17u + q]; if (!found) { if (k < pc) { j = q; found = true; } else k -= pc; } }
+        if (found) { const uint32_t a0 = j * chunk, a1 = (a0 + chunk) < mw ? (a0 + chunk) : mw; action = Ops<NL, W>::kth_set_bit(lds_masks + (size_t)lane * ldw, a0, a1, k); }
+    }
+    actions[g] = action; totals[g] = total;
+}
+template <int NL, int W>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_step_action(Consts<NL> C, Quad* soa, uint32_t n, const uint32_t* actions, const uint32_t* totals, tafl_play* out_plays, tafl_effects* eff) {
+    const uint32_t g = blockIdx.x * TAFL_BLOCK + threadIdx.x;
+    if (g >= n) return;
+    DState<NL> st; StateIO<NL>::load_soa(soa, n, g, st);
     tafl_effects e; tafl_play p;
-    Ops<NL, W>::step_kth_finish(st, ranks[g], lds_cnt[lane], C, &p, &e, lds_masks + (size_t)lane * ldw, mw);
+    Ops<NL, W>::step_action(st, actions[g], totals[g], C, &p, &e);
     StateIO<NL>::store_soa(soa, n, g, st);
     if (eff) eff[g] = e;
     if (out_plays) out_plays[g] = p;
@@ -513,7 +577,8 @@ struct tafl_ctx {
     hipStream_t stream;
     bool own_stream;
     Consts<2> c2; Consts<4> c4; Consts<8> c8;
-    Consts<6> c6;                    // the 13x13 preset in the dense 13-column search layout (preset == PRESET_COPENHAGEN13 only)
+    Consts<6> c6;                    // the same rules in the dense 13-column layout (dense13: 256-bit words, side_len <= 13)
+    bool dense13;
     int preset;                      // PRESET_* detected at ctx_create: selects kernels with compile-time constants
     uint32_t live_batches;           // batches created on this context and not yet destroyed (tafl_ctx_destroy refuses while > 0)
     uint32_t rollout_capacity;       // playouts k_mcts_rollout holds on the device at once (occupancy x CUs x 64 lanes); 0 = not asked yet
@@ -682,7 +747,8 @@ int tafl_ctx_create(const tafl_rules* rules, uint8_t side_len, uint32_t word_bit
     if (c->nl == 2) rc = make_consts<2, 7>(*rules, side_len, c->c2);
     else if (c->nl == 4) rc = make_consts<4, 11>(*rules, side_len, c->c4);
     else rc = make_consts<8, 15>(*rules, side_len, c->c8);
-    if (!rc && c->preset == PRESET_COPENHAGEN13) rc = make_consts<6, 13>(*rules, side_len, c->c6);
+    c->dense13 = c->nl == 8 && side_len <= 13;      // the 13-column layout holds the board: streamed steps and the 13x13 preset's searches use it
+    if (!rc && c->dense13) rc = make_consts<6, 13>(*rules, side_len, c->c6);
     if (rc) { delete c; return fail(TAFL_ERR_INVALID_ARG, "bad rules / geometry"); }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(TAFL_ERR_HIP, "hipStreamCreate failed"); } c->own_stream = true; }
@@ -858,7 +924,7 @@ int tafl_movegen(tafl_batch* b, uint32_t* out_counts, uint32_t* out_masks) {
     {
         SpanGuard sg(c, KC_MOVEGEN);
         if (out_masks) {
-            DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen_masks<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK * TAFL_MG_WAVES), TAFL_BLOCK * ((mw | 1u) + 1u) * sizeof(uint32_t), c->stream,
+            DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen_masks<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK * c->n), TAFL_BLOCK * ((mw | 1u) + 1u) * sizeof(uint32_t), c->stream,
                                                CC, b->soa, n, (uint32_t*)b->counts.p, (uint32_t*)b->masks.p, mw));
         } else {
             DISPATCH_NLW(c, hipLaunchKernelGGL((k_movegen<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, (uint32_t*)b->counts.p));
@@ -894,7 +960,9 @@ int tafl_step(tafl_batch* b, const tafl_play* plays, tafl_effects* out_effects) 
     HIPCHK(hipMemcpyAsync(b->plays.p, plays, sizeof(tafl_play) * n, hipMemcpyHostToDevice, c->stream));
     {
         SpanGuard sg(c, KC_STEP);
-        DISPATCH_NLW(c, hipLaunchKernelGGL((k_step<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
+        if (c->dense13) hipLaunchKernelGGL(k_step_dense13, dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, c->c8, c->c6, b->soa, n,
+                                           (const tafl_play*)b->plays.p, out_effects ? (tafl_effects*)b->effects.p : nullptr);
+        else DISPATCH_NLW(c, hipLaunchKernelGGL((k_step<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n,
                                            (const tafl_play*)b->plays.p, out_effects ? (tafl_effects*)b->effects.p : nullptr));
     }
     HIPCHK(hipGetLastError());
@@ -907,15 +975,19 @@ int tafl_step_kth(tafl_batch* b, const uint32_t* ranks, tafl_play* out_plays, ta
     if (!b || !ranks) return fail(TAFL_ERR_INVALID_ARG, "null argument");
     tafl_ctx* c = b->ctx; const uint32_t n = b->n;
     HIPCHK(hipSetDevice(c->device));
-    NEED(b->ranks, sizeof(uint32_t) * n);
+    NEED(b->ranks, sizeof(uint32_t) * n); NEED(b->counts, sizeof(uint32_t) * 2 * (size_t)n);      // counts: chosen action and number of plays per game
     if (out_plays) NEED(b->out_plays, sizeof(tafl_play) * n);
     if (out_effects) NEED(b->effects, sizeof(tafl_effects) * n);
     HIPCHK(hipMemcpyAsync(b->ranks.p, ranks, sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
     {
         SpanGuard sg(c, KC_STEP);
-        DISPATCH_NLW(c, hipLaunchKernelGGL((k_step_kth<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK * TAFL_MG_WAVES), TAFL_BLOCK * ((tafl_action_mask_words(c) | 1u) + 1u) * sizeof(uint32_t), c->stream,
-                                           CC, b->soa, n, (const uint32_t*)b->ranks.p, out_plays ? (tafl_play*)b->out_plays.p : nullptr,
-                                           out_effects ? (tafl_effects*)b->effects.p : nullptr, tafl_action_mask_words(c)));
+        const uint32_t mw = tafl_action_mask_words(c);
+        DISPATCH_NLW(c, hipLaunchKernelGGL((k_select_kth<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK * c->n), TAFL_BLOCK * ((mw | 1u) + 1u + 17u) * sizeof(uint32_t), c->stream,
+                                           CC, b->soa, n, (const uint32_t*)b->ranks.p, (uint32_t*)b->counts.p, (uint32_t*)b->counts.p + n, mw));
+        if (c->dense13) hipLaunchKernelGGL(k_step_action_dense13, dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, c->c8, c->c6, b->soa, n, (const uint32_t*)b->counts.p,
+                                           (const uint32_t*)b->counts.p + n, out_plays ? (tafl_play*)b->out_plays.p : nullptr, out_effects ? (tafl_effects*)b->effects.p : nullptr);
+        else DISPATCH_NLW(c, hipLaunchKernelGGL((k_step_action<NL, W>), dim3(grid_of(n)), dim3(TAFL_BLOCK), 0, c->stream, CC, b->soa, n, (const uint32_t*)b->counts.p,
+                                           (const uint32_t*)b->counts.p + n, out_plays ? (tafl_play*)b->out_plays.p : nullptr, out_effects ? (tafl_effects*)b->effects.p : nullptr));
     }
     HIPCHK(hipGetLastError());
     if (out_plays) HIPCHK(hipMemcpyAsync(out_plays, b->out_plays.p, sizeof(tafl_play) * n, hipMemcpyDeviceToHost, c->stream));

@@ -149,101 +149,104 @@ struct Ops {
 
     // ---- tafl_movegen: count + dense action mask ------------------------------------------------------------------------------
     // The dense mask holds, per source tile, one field of 2(n-1) bits: [V+ distances 1..n-1-r][V- 1..r][H+ 1..n-1-c][H- 1..c]
-    // (include/taflhip.h).  It is written one DIRECTION at a time and, inside a direction, one PIECE at a time: all plays of a piece in
-    // one direction are the tiles of that direction's reach set between the piece and the first occupied tile behind them (a tile of the
-    // reach set belongs to the nearest piece behind it), i.e. one small bit field per piece instead of one resolve per destination.
-    // On the device four waves (one per direction) work on the same 64 games side by side and OR their fields into LDS.
-
-    // reach set of the side to move restricted to one direction (Engine::movegen is the four of them)
-    template <int DIR> static TAFL_HD Bits<NL> movegen_dir(const S& st, uint32_t side, const K& C) {
-        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return bz<NL>();            // logic.rs:165-167
-        const Bits<NL> occ = st.att | st.def, empty = andn(C.board, occ);
-        auto cls = [&](const Bits<NL>& gen, int c) {
-            return E::template ray_reach<DIR>(gen, andn(empty, C.pass_forbid[c]), andn(empty, C.land_forbid[c]), C.slow[c] != 0, C);
-        };
-        if (side == 0) return cls(st.att & C.board, CLS_ATT);
-        if (C.king_like_soldier) return cls(st.def & C.board, CLS_DEF);
-        const Bits<NL> kb = E::king_bit(st, C);
-        Bits<NL> r = cls(andn(st.def & C.board, kb), CLS_DEF);
-        if (any(kb)) r |= cls(kb, CLS_KING);
-        return r;
-    }
+    // (include/taflhip.h).  It is written one LINE of the board at a time: pass `i` serves the horizontal plays of the pieces in row i (its
+    // occupancy is n contiguous bits of the position) and the vertical plays of the pieces in column i (n bits gathered at stride W).  On a
+    // line the plays of one piece in one direction are the tiles between it and the first occupied tile (ValidPlayIterator, play.rs:189-225):
+    //   run   = the empty tiles from the piece outwards up to the first occupied tile or the board's end,
+    //           cut behind the first tile the piece may not pass (pass_forbid: NoPass / KingPass throne; the tile itself stays),
+    //   plays = run minus the tiles it may not stop on (land_forbid: corners, throne by rule); a slow piece keeps distance 1 only
+    // - a handful of 32-bit operations per piece and direction, no reach set of the whole position and no mirrored position (round 2 built
+    // both: ~180 wave-instructions per game, now ~70).  On the device a workgroup serves 64 games with one WAVE PER LINE (lane = game): the
+    // line index is wave-uniform, so every bit position below is a scalar, and the fields are OR-ed into the game's mask in LDS.
+    // land_forbid / pass_forbid are made of corners and throne (make_consts_ct), sets that equal their mirror image: column i of them is row i.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define TAFL_MASK_OR(p, v) atomicOr((p), (v))          /* four waves write one game's mask */
+#define TAFL_MASK_OR(p, v) atomicOr((p), (v))          /* the waves of a workgroup write one game's mask */
 #else
 #define TAFL_MASK_OR(p, v) (*(p) |= (v))
 #endif
-    // row `R0` (compile time) of a board word as an n-bit value
-    template <int R0> static TAFL_HD uint32_t rowbits(const Bits<NL>& a) {
-        constexpr int pos = R0 * W, wi = pos >> 5, off = pos & 31;
-        uint32_t v = a.w[wi] >> off;
-        if constexpr (off + W > 32 && wi + 1 < NL) v |= a.w[wi + 1] << (32 - off);
-        return v & ((1u << W) - 1u);
+    // n (<= 15) bits of `a` from bit `base`
+    static TAFL_HD uint32_t line_bits(const Bits<NL>& a, uint32_t base, uint32_t n) { return (uint32_t)field64<0>(a, base) & ((1u << n) - 1u); }
+    // column `c` of a board word as an n-bit value (bit k = row k): the word moved c (< W <= 15) bits down, one funnel shift per limb, puts
+    // tile (k, c) at the fixed bit k * W (off-board rows read as 0: board words hold no bits there)
+    static TAFL_HD uint32_t col_bits(const Bits<NL>& a, uint32_t c, uint32_t n) {
+        (void)n;
+        Bits<NL> sft;
+        TAFL_UNROLL for (int i = 0; i < NL; ++i) sft.w[i] = (a.w[i] >> c) | ((c != 0u && i + 1 < NL) ? (a.w[i + 1 < NL ? i + 1 : i] << ((32u - c) & 31u)) : 0u);
+        uint32_t v = 0;
+        TAFL_UNROLL for (int k = 0; k < W; ++k) v |= ((sft.w[(k * W) >> 5] >> ((k * W) & 31)) & 1u) << k;
+        return v;
     }
-    // the position mirrored at the main diagonal (tile (r, c) -> (c, r)): a vertical play of `st` is a horizontal play of the mirror image,
-    // and every rule mask (board, corners, throne and what derives from them) is symmetric, so the same row code serves both axes
-    static TAFL_HD void transpose_state(const S& st, S& t) {
-        t = st;
-        t.att = bz<NL>(); t.def = bz<NL>();
-        Bits<NL> p = st.att;
-        while (any(p)) { const uint32_t i = lsb(p); p = andn(p, bit_at<NL>(i)); t.att |= bit_at<NL>(Fast<NL, W>::n_to_t(i)); }
-        p = st.def;
-        while (any(p)) { const uint32_t i = lsb(p); p = andn(p, bit_at<NL>(i)); t.def |= bit_at<NL>(Fast<NL, W>::n_to_t(i)); }
-        t.flags = (st.flags & ~0x00FF0000u) | (TAFL_F_KCOL(st.flags) << 16) | (TAFL_F_KROW(st.flags) << 20);
+    // one line as the rays see it: occupancy, land_forbid and pass_forbid bits of its n tiles, and the same three mirrored (tile n-1-k at bit
+    // k), so that a ray towards lower positions is a ray towards higher positions of the mirror image
+    struct LineView { uint32_t occ, lf, pf, occ_m, lf_m, pf_m; };
+    static TAFL_HD uint32_t mirror_n(uint32_t v, uint32_t n) { return bitrev32(v) >> (32u - n); }
+    // plays of the piece at position p of a line towards higher positions, bit k = distance k + 1
+    static TAFL_HD uint32_t ray_up(uint32_t occ, uint32_t lf, uint32_t pf, uint32_t p, uint32_t n) {
+        const uint32_t ext = n - 1u - p;                                 // tiles beyond p (<= 14)
+        const uint32_t f = ~(occ >> (p + 1u)) & ((1u << ext) - 1u);       // empty tiles, nearest first
+        const uint32_t t = ~f;                                           // (bit ext of t is set: the run ends at the board's end at the latest)
+        uint32_t run = (t & (0u - t)) - 1u;
+        const uint32_t pfb = (pf >> (p + 1u)) & run, cut = pfb & (0u - pfb);
+        run = pfb ? (run & ((cut << 1) - 1u)) : run;
+        return run & ~(lf >> (p + 1u));
     }
-    // one row of horizontal plays: every piece of `mine` in row R0 gets the field of its plays to the right (PLUS) or left, cut out of the
-    // row of the reach set between the piece and the first occupied tile behind it.  TR: the position is the mirror image (vertical plays).
-    template <int R0, bool PLUS, bool TR> static TAFL_HD void row_fields(const Bits<NL>& R, const Bits<NL>& occ, const Bits<NL>& mine, uint32_t n, uint32_t* row) {
-        const uint32_t rowR = rowbits<R0>(R);
-        if (rowR == 0) return;
-        const uint32_t rowO = rowbits<R0>(occ), nm = n - 1u;
-        uint32_t m = rowbits<R0>(mine);
-        while (m) {
-            const uint32_t c = (uint32_t)__builtin_ctz(m);
-            m &= m - 1u;
-            uint32_t field;
-            if constexpr (PLUS) {
-                const uint32_t lm = (1u << (nm - c)) - 1u;
-                const uint32_t bl = (rowO >> (c + 1u)) & lm;                     // pieces further along the row
-                field = (rowR >> (c + 1u)) & ((bl & (0u - bl)) - 1u) & lm;       // reach tiles before the first of them
-            } else {
-                if (c == 0) continue;
-                const uint32_t lm = (1u << c) - 1u, sh = 32u - c;
-                const uint32_t bl = bitrev32((rowO & lm) << sh);                 // the row segment before the piece, nearest tile first
-                field = bitrev32((rowR & lm) << sh) & ((bl & (0u - bl)) - 1u) & lm;
+    // Pass `I` of the dense mask: horizontal plays of the pieces in row I and vertical plays of the pieces in column I.  Returns their number;
+    // ORs them into `row` (the game's mask) unless it is null.  (The line index is a template parameter: every bit position is then a
+    // literal; movegen_line dispatches on the run-time index, which is wave-uniform on the device.)  The pieces of the row and of the column
+    // go through ONE loop: 64 games share an instruction stream, and the largest sum of two counts is smaller than the sum of the largest.
+    template <int I> static TAFL_HD uint32_t movegen_line_ct(const S& st, const K& C, uint32_t* row) {
+        constexpr uint32_t i = (uint32_t)I, base = (uint32_t)(I * W);
+        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return 0;                   // logic.rs:165-167
+        const uint32_t side = st.flags & TAFL_F_SIDE, n = C.n, nm = n - 1u;
+        const Bits<NL> occ = (st.att | st.def) & C.board, mine = (side ? st.def : st.att) & C.board;
+        const int scls = side ? CLS_DEF : CLS_ATT;
+        // rule masks of line I for the soldiers of the side and for the king (column I of them = row I: the sets equal their mirror image)
+        const uint32_t s_lf = line_bits(C.land_forbid[scls], base, n), s_pf = line_bits(C.pass_forbid[scls], base, n);
+        const uint32_t k_lf = line_bits(C.land_forbid[CLS_KING], base, n), k_pf = line_bits(C.pass_forbid[CLS_KING], base, n);
+        const uint32_t s_lf_m = mirror_n(s_lf, n), s_pf_m = mirror_n(s_pf, n), k_lf_m = mirror_n(k_lf, n), k_pf_m = mirror_n(k_pf, n);
+        const bool s_slow = C.slow[scls] != 0, k_slow = C.slow[CLS_KING] != 0;
+        // the king: a defender on the tile the king nibble names (board/state.rs:24-26); his own rule masks only where they differ
+        const uint32_t kr = TAFL_F_KROW(st.flags), kc = TAFL_F_KCOL(st.flags);
+        const bool kingside = side != 0 && !C.king_like_soldier;
+        const uint32_t ro = line_bits(occ, base, n), co = col_bits(occ, i, n);
+        const uint32_t ro_m = mirror_n(ro, n), co_m = mirror_n(co, n);
+        const uint32_t kpos_r = (kingside && kr == i) ? kc : 0xFFu, kpos_c = (kingside && kc == i) ? kr : 0xFFu;       // the king's place on the row / the column
+        // items: bit p = piece at position p of the row, bit 16 + p = piece at position p of the column
+        uint32_t items = line_bits(mine, base, n) | (col_bits(mine, i, n) << 16);
+        uint32_t cnt = 0;
+        while (items) {
+            const uint32_t it = (uint32_t)__builtin_ctz(items);
+            items &= items - 1u;
+            const bool col = it >= 16u;
+            const uint32_t p = it & 15u;
+            const bool isk = p == (col ? kpos_c : kpos_r);
+            const uint32_t lo = col ? co : ro, lo_m = col ? co_m : ro_m;
+            const uint32_t lf = isk ? k_lf : s_lf, pf = isk ? k_pf : s_pf, lf_m = isk ? k_lf_m : s_lf_m, pf_m = isk ? k_pf_m : s_pf_m;
+            uint32_t up = ray_up(lo, lf, pf, p, n), dn = ray_up(lo_m, lf_m, pf_m, nm - p, n);
+            if (isk ? k_slow : s_slow) { up &= 1u; dn &= 1u; }
+            const uint32_t both = up | (dn << (nm - p));                             // [+ distances 1..n-1-p][- distances 1..p]: n-1 bits
+            if (both == 0u) continue;
+            cnt += (uint32_t)__builtin_popcount(both);
+            if (row) {
+                // source tile (r, c) and the first slot of this axis inside its 2(n-1)-bit field: V at 0, H at n-1
+                const uint32_t t_o = col ? mul24(p, n) + i : i * n + p;
+                const uint32_t a0 = mul24(t_o, 2u * nm) + (col ? 0u : nm), w = a0 >> 5, sh2 = a0 & 31u;
+                TAFL_MASK_OR(&row[w], both << sh2);
+                if (sh2 != 0u && (both >> (32u - sh2)) != 0u) TAFL_MASK_OR(&row[w + 1u], both >> (32u - sh2));
             }
-            if (field == 0) continue;
-            // source tile (r, c) of the ORIGINAL position and the first slot of this direction inside its 2(n-1)-bit field
-            const uint32_t r_o = TR ? c : (uint32_t)R0, c_o = TR ? (uint32_t)R0 : c;
-            const uint32_t slot0 = TR ? (PLUS ? 0u : nm - r_o) : (PLUS ? nm : nm + (nm - c_o));
-            const uint32_t a0 = mul24(mul24(r_o, n) + c_o, 2u * nm) + slot0, w = a0 >> 5, sh2 = a0 & 31u;
-            TAFL_MASK_OR(&row[w], field << sh2);
-            if (sh2 != 0 && (field >> (32u - sh2)) != 0) TAFL_MASK_OR(&row[w + 1u], field >> (32u - sh2));
         }
-    }
-    template <int R0, bool PLUS, bool TR> static TAFL_HD void all_row_fields(const Bits<NL>& R, const Bits<NL>& occ, const Bits<NL>& mine, uint32_t n, uint32_t* row) {
-        if constexpr (R0 < W) {
-            if ((uint32_t)R0 < n) row_fields<R0, PLUS, TR>(R, occ, mine, n, row);
-            all_row_fields<R0 + 1, PLUS, TR>(R, occ, mine, n, row);
-        }
-    }
-    // plays of the side to move in direction DIR: returns their number and, if `row` is not null, ORs them into the game's dense mask
-    template <int DIR> static TAFL_HD uint32_t movegen_fields(const S& st, const K& C, uint32_t* row) {
-        const uint32_t side = st.flags & TAFL_F_SIDE;
-        if (!row) return popc(movegen_dir<DIR>(st, side, C));
-        if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return 0;
-        constexpr bool TR = DIR == DIR_VP || DIR == DIR_VM, PLUS = DIR == DIR_VP || DIR == DIR_HP;
-        S t;
-        if constexpr (TR) transpose_state(st, t); else t = st;
-        const Bits<NL> R = movegen_dir<PLUS ? DIR_HP : DIR_HM>(t, side, C);
-        const uint32_t cnt = popc(R);
-        if (cnt == 0) return 0;
-        all_row_fields<0, PLUS, TR>(R, (t.att | t.def) & C.board, (side ? t.def : t.att) & C.board, C.n, row);
         return cnt;
+    }
+    template <int I = 0> static TAFL_HD uint32_t movegen_line(const S& st, uint32_t i, const K& C, uint32_t* row) {
+        if constexpr (I >= W) return 0;
+        else return i == (uint32_t)I ? movegen_line_ct<I>(st, C, row) : movegen_line<I + 1>(st, i, C, row);
     }
     // count + dense action mask of one position (mask may be null; it must be zero-initialised by the caller)
     static TAFL_HD uint32_t movegen(const S& st, const K& C, uint32_t* mask) {
-        return movegen_fields<DIR_VP>(st, C, mask) + movegen_fields<DIR_VM>(st, C, mask) + movegen_fields<DIR_HP>(st, C, mask) + movegen_fields<DIR_HM>(st, C, mask);
+        if (!mask) { Moves<NL> mv; E::movegen(st, st.flags & TAFL_F_SIDE, C, mv); return mv.total; }       // counts alone: four reach sets, popcount
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < C.n; ++i) cnt += movegen_line(st, i, C, mask);
+        return cnt;
     }
     static TAFL_HD int validate(const S& st, tafl_play p, const K& C) { return E::validate(st, p, st.flags & TAFL_F_SIDE, C, nullptr); }
     static TAFL_HD bool side_can_play(const S& st, uint32_t side, const K& C) {
@@ -276,31 +279,34 @@ struct Ops {
     }
     // The (rank mod count)-th legal play in canonical order = the (rank mod count)-th set bit of the dense action mask (the
     // action index preserves the canonical order).  `mask`: zeroed scratch of mask_words words (LDS on the device).
+    static constexpr uint32_t NO_ACTION = 0xFFFFFFFFu;
+    // k-th (0-based) set bit of words [w0, w1) of the mask, k < their popcount; NO_ACTION if count and mask disagree (surfaced by the tests)
+    static TAFL_HD uint32_t kth_set_bit(const uint32_t* mask, uint32_t w0, uint32_t w1, uint32_t k) {
+        uint32_t a = NO_ACTION; bool found = false;
+        for (uint32_t w = w0; w < w1; ++w) {
+            const uint32_t v = mask[w], c = (uint32_t)__builtin_popcount(v);
+            if (!found) { if (k < c) { a = w * 32u + nth_set_bit32(v, k); found = true; } else k -= c; }
+        }
+        return a;
+    }
     static TAFL_HD void step_kth(S& st, uint32_t rank, const K& C, tafl_play* out_play, tafl_effects* eff, uint32_t* mask, uint32_t mask_words) {
         const uint32_t total = movegen(st, C, mask);
-        step_kth_finish(st, rank, total, C, out_play, eff, mask, mask_words);
+        step_action(st, total ? kth_set_bit(mask, 0, mask_words, rank % total) : NO_ACTION, total, C, out_play, eff);
     }
-    // second half of step_kth: `mask` holds the dense legal mask of `st`, `total` its number of legal plays
-    static TAFL_HD void step_kth_finish(S& st, uint32_t rank, uint32_t total, const K& C, tafl_play* out_play, tafl_effects* eff, const uint32_t* mask, uint32_t mask_words) {
+    // second half of step_kth: `action` = the chosen play as a dense action index (NO_ACTION: the side has no play), `total` its number of plays
+    static TAFL_HD void step_action(S& st, uint32_t action, uint32_t total, const K& C, tafl_play* out_play, tafl_effects* eff) {
         tafl_effects e; caps_to_effects(bz<NL>(), 0, e);
         tafl_play pl; pl.from_row = pl.from_col = pl.axis = 0; pl.disp = 0;
         int code;
         if (total == 0) code = TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING ? TAFL_PLAY_GAME_OVER : TAFL_PLAY_NO_PIECE;
-        else {
-            uint32_t k = rank % total, a = 0; bool found = false;
-            for (uint32_t w = 0; w < mask_words; ++w) {
-                const uint32_t v = mask[w], c = (uint32_t)__builtin_popcount(v);
-                if (!found) { if (k < c) { a = w * 32u + nth_set_bit32(v, k); found = true; } else k -= c; }
-            }
-            if (found) {
-                const Move m = move_of_action(a, C);
-                pl = to_play(m);
-                StepOut<NL> so; Moves<NL> nx;
-                E::apply(st, m, C, &so, nx);
-                caps_to_effects(so.captures, so.n_captures, e);
-                code = TAFL_PLAY_OK;
-            } else code = TAFL_PLAY_NO_PIECE;     // count and mask disagree: surfaced by the tests
-        }
+        else if (action != NO_ACTION) {
+            const Move m = move_of_action(action, C);
+            pl = to_play(m);
+            StepOut<NL> so; Moves<NL> nx;
+            E::apply(st, m, C, &so, nx);
+            caps_to_effects(so.captures, so.n_captures, e);
+            code = TAFL_PLAY_OK;
+        } else code = TAFL_PLAY_NO_PIECE;         // count and mask disagree: surfaced by the tests
         status_to_effects(st, code, e);
         if (eff) *eff = e;
         if (out_play) *out_play = pl;
