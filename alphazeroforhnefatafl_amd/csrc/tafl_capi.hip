@@ -50,7 +50,9 @@ extern "C" int tafl_prof_read(unsigned long long* out, int reset) {
 static_assert(TAFL_MCTS_MAX_SLOTS == tafl::kMctsMaxSlots, "slot bound of tafl_ops.hpp");
 #define TAFL_MCTS_MAX_PARTS 8         /* partitions of a batch that run the two-kernel pipeline on their own streams */
 #define TAFL_MCTS_TRACE_ROUNDS 4096   /* rounds of a search whose work counts are kept for tafl_mcts_round_trace */
-#define TAFL_MCTS_UNDO_CAP 64        /* undo records per game and speculation pass (edges and headers each) */
+#define TAFL_MCTS_UNDO_CAP 16        /* undo records per game and prediction pass (edges and headers each), in LDS: 16 x 14 words x 64 lanes = 56 KiB per tree wave */
+#define TAFL_MCTS_UNDO_CAP_FUSED 5   /* the fused kernel predicts one simulation (two slots) and runs eight waves per CU: 17.5 KiB per wave */
+#define TAFL_UNDO_LDS_BYTES(cap) ((size_t)(cap) * (tafl::kUndoEWords + tafl::kUndoHWords) * TAFL_BLOCK * sizeof(uint32_t))
 
 template <int NL, int W>
 __global__ __launch_bounds__(TAFL_BLOCK) void k_fill(Quad* soa, uint32_t n, DState<NL> st) {
@@ -302,7 +304,10 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
     if (round < planned) rounds_left = planned - round;
     else rounds_left = (probe_every == 0u || 4ull * ld_counter(&stats[ST_DONE]) >= 3ull * (unsigned long long)M.G) ? 1u : 0u;
     const uint32_t wcap = (uint32_t)ld_counter(&ctrl[CT_WCAP]);
-    if (live) Ops<NL, W>::mcts_tree_step(M, g, c_puct, n_sims, rounds_left, target, wcap, C, ls);
+    // the undo log of the prediction pass: LDS, one log per lane, word-interleaved (tafl_ops.hpp LogMem)
+    extern __shared__ uint32_t tree_lds[];
+    LogMem lm; lm.base = tree_lds; lm.stride = TAFL_BLOCK; lm.lane = threadIdx.x & 63u; lm.cap = TAFL_MCTS_UNDO_CAP;
+    if (live) Ops<NL, W>::mcts_tree_step(M, g, c_puct, n_sims, rounds_left, target, wcap, C, ls, lm);
     {   // games that completed their last simulation in this launch (a finished game is never live again: counted once)
         const unsigned long long fin = __ballot(live && M.sim_next[g] >= n_sims && M.kind[g] != 1);
         if ((threadIdx.x & 63u) == 0 && fin) atomicAdd(&stats[ST_DONE], (unsigned long long)__popcll(fin));
@@ -394,10 +399,12 @@ __global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_m
     LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
     ls.reason_hist4 = 0; ls.spec_issued = ls.spec_hits = 0;
     uint32_t executed = 0, finished = 0;
+    extern __shared__ uint32_t tree_lds[];                        // undo log of the prediction pass (tafl_ops.hpp LogMem)
+    LogMem lm; lm.base = tree_lds; lm.stride = TAFL_BLOCK; lm.lane = lane; lm.cap = K > 1 ? TAFL_MCTS_UNDO_CAP_FUSED : 0u;
     for (uint32_t round = 0; round < max_rounds; ++round) {
         const bool live = lane < GPW && tg < M.G && (M.sim_next[tg] < n_sims || M.kind[tg] == 1);
         if (__ballot(live) == 0ull) break;                        // every game of this wave has finished
-        if (live) Ops<NL, W>::mcts_tree_step(M, tg, c_puct, n_sims, 0u, 0u, K, C, ls);
+        if (live) Ops<NL, W>::mcts_tree_step(M, tg, c_puct, n_sims, 0u, 0u, K, C, ls, lm);
         finished += (uint32_t)__popcll(__ballot(live && M.sim_next[tg] >= n_sims && M.kind[tg] != 1));
         if ((round & 3u) == 3u) {                                 // the packed 4-bit reason counters hold 15: at most 2 playouts are consumed per round
             for (uint32_t r = 0; r < 16; ++r) stat_add(stats, ST_REASON0 + r, (uint32_t)((ls.reason_hist4 >> (4u * r)) & 15ull));
@@ -633,7 +640,7 @@ struct tafl_batch {
     DevBuf best_plays, best_visits, enc, policy;
     DevBuf work, work_count, trace;
     uint32_t trace_rounds;           // rounds of the last two-kernel search recorded in `trace` (requested / run playouts per round)
-    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_node, spec_ord, spec_first, spec_n, spec_w, ulog_e, ulog_h;
+    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_node, spec_ord, spec_first, spec_n, spec_w;
     uint32_t spec_k;                 // playout slots per game that exist (TAFL_MCTS_MAX_SLOTS)
     tafl_mcts_stats last_stats; bool ran;
     // guided MCTS (external evaluator)
@@ -845,7 +852,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_meta, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->ulog_e, &b->ulog_h, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl,
+                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
                       &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
     for (DevBuf* d : bufs) d->release();
@@ -1056,7 +1063,6 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_node, k * n * 4); NEED(b->spec_ord, k * n * 4); NEED(b->spec_first, n * 4);
     NEED(b->spec_n, n); NEED(b->spec_w, n); NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
     NEED(b->ctrl, sizeof(unsigned long long) * CT_COUNT);
-    NEED(b->ulog_e, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoE)); NEED(b->ulog_h, (size_t)TAFL_MCTS_UNDO_CAP * n * sizeof(UndoH));
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
     b->mem.kind = (uint8_t*)b->kind.p; b->mem.fault = (uint8_t*)b->fault.p;
@@ -1064,7 +1070,6 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
     b->mem.spec_node = (uint32_t*)b->spec_node.p; b->mem.spec_ord = (uint32_t*)b->spec_ord.p; b->mem.spec_first = (uint32_t*)b->spec_first.p;
     b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_w = (uint8_t*)b->spec_w.p; b->mem.spec_k = b->spec_k;
-    b->mem.ulog_e = (UndoE*)b->ulog_e.p; b->mem.ulog_h = (UndoH*)b->ulog_h.p; b->mem.ulog_cap = TAFL_MCTS_UNDO_CAP;
     b->mem.G = b->n; b->mem.node_cap = (uint32_t)node_cap; b->mem.edge_cap = (uint32_t)edge_cap;
     b->mem.flags = 0;
     b->has_mem = true; b->reserved_sims = max_sims;
@@ -1105,7 +1110,7 @@ static int mcts_enqueue_rounds(tafl_batch* b, uint32_t count, bool stagger) {
             uint32_t* wc_now = pk.wc + (i & 1u) * TAFL_MCTS_MAX_SLOTS; uint32_t* wc_next = pk.wc + ((i + 1u) & 1u) * TAFL_MCTS_MAX_SLOTS;
             {
                 SpanGuard sg(c, KC_MCTS_TREE, pk.s);
-                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), 0, pk.s, CC, M, p->c_puct, p->n_sims, i, sp.planned, sp.probe_every,
+                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), TAFL_UNDO_LDS_BYTES(TAFL_MCTS_UNDO_CAP), pk.s, CC, M, p->c_puct, p->n_sims, i, sp.planned, sp.probe_every,
                                                       sp.slots, st, ctrl, pk.wl, wc_now, pk.g0, pk.g1));
             }
             // partition k+1 starts behind partition k's first tree launch: from then on the tree phases are spread over a round
@@ -1136,10 +1141,10 @@ static int mcts_enqueue_fused(tafl_batch* b, uint32_t rounds) {
     SpanGuard sg(c, KC_MCTS_ROLLOUT, s0);
     constexpr int NL = 2, W = 7; const Consts<2>& CC = c->c2;
     if (c->preset == PRESET_BRANDUBH7) {
-        if (sp.slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
+        if (sp.slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), TAFL_UNDO_LDS_BYTES(TAFL_MCTS_UNDO_CAP_FUSED), s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
         else hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_BRANDUBH7, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
     } else {
-        if (sp.slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), 0, s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
+        if (sp.slots == 2) hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 2>), dim3((n + 31) / 32), dim3(TAFL_BLOCK), TAFL_UNDO_LDS_BYTES(TAFL_MCTS_UNDO_CAP_FUSED), s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
         else hipLaunchKernelGGL((k_mcts_fused<NL, W, PRESET_NONE, 1>), dim3(bps), dim3(TAFL_BLOCK), 0, s0, CC, M, p->c_puct, p->n_sims, p->seed, sp.base, p->sim_offset, p->max_rollout_plies, rounds, st);
     }
     sp.next_round += rounds;

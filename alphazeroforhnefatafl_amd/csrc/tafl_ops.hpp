@@ -70,8 +70,11 @@ struct alignas(16) Edge { double q; uint32_t n; uint32_t child; };   // Qsa, Nsa
 
 // undo records of the speculation pass (mcts_speculate): the tree is modified in place by ASSUMED playout values to predict the next
 // selections and then restored bit for bit
-struct UndoE { uint32_t idx; uint32_t _pad[3]; Edge e; };  // 32 bytes: edge index inside the game's arena + its old contents
-struct UndoH { uint32_t node; uint32_t _pad[3]; NodeHdr h; };   // 48 bytes
+// The undo log lives in the caller's scratch - LDS on the device, one log per lane - as word-interleaved records: word k of record i of lane
+// l at base[(i * WORDS + k) * stride + l] (stride = lanes that share the scratch: consecutive lanes hit consecutive LDS banks).
+constexpr uint32_t kUndoEWords = 5;       // edge index inside the game's arena + the edge's old contents (q lo, q hi, n, child)
+constexpr uint32_t kUndoHWords = 9;       // node id + the header's old contents (8 words)
+struct LogMem { uint32_t* base; uint32_t stride, lane, cap; };       // cap records of each kind: cap * (kUndoEWords + kUndoHWords) * stride words
 
 struct MctsMem {
     Quad* node_state;            // [(k * G + g) * QUADS]
@@ -99,9 +102,7 @@ struct MctsMem {
     uint8_t* spec_n;             // [G] slots issued (placeholders of predicted terminal revisits included)
     uint8_t* spec_w;             // [G] speculative slots this game may issue next (grows by one per fully consumed issue, shrinks to
                                  //     what was consumed + 1 after a misprediction)
-    UndoE* ulog_e;               // [g * ulog_cap + i]
-    UndoH* ulog_h;               // [g * ulog_cap + i]
-    uint32_t G, node_cap, edge_cap, spec_k, ulog_cap;      // spec_k: slots per game that exist (capacity of the arrays above)
+    uint32_t G, node_cap, edge_cap, spec_k;      // spec_k: slots per game that exist (capacity of the arrays above)
     uint32_t flags;              // TAFL_MCTS_FLAG_* semantics bits of the running search
 };
 
@@ -366,6 +367,7 @@ struct Ops {
         bool pos_valid;
     };
     static_assert(sizeof(NodeHdr) == 32, "NodeHdr is eight words");
+    static_assert(sizeof(Edge) == 16, "Edge is four words");
     struct StepCtx { uint32_t node_top, edge_top; RootCache rc; };
     struct SlotView { bool valid; uint8_t kind, reason; int8_t value; uint32_t node, ord, meta, plies; };
     struct SimOut {
@@ -585,18 +587,22 @@ struct Ops {
     static constexpr uint32_t VIRT_CHILD = 0xFFFFFFFFu;       // child id of an edge that exists only during the speculation pass
     static constexpr uint32_t ORD_SELF = 0xFFFFFFFFu;         // spec_ord of slot 0: the slot's leaf is spec_node itself
 
-    struct SpecLog {                                          // undo log of one speculation pass (global memory, per game)
-        UndoE* e; UndoH* h; uint32_t ne, nh, cap; bool ok;
+    struct SpecLog {                                          // undo log of one speculation pass (LogMem: the caller's scratch)
+        uint32_t* eb; uint32_t* hb; uint32_t stride, ne, nh, cap; bool ok;
     };
     static TAFL_HD void log_edge(SpecLog& L, uint32_t eidx, const Edge& old) {
         if (L.ne >= L.cap) { L.ok = false; return; }
-        UndoE u; u.idx = eidx; u._pad[0] = u._pad[1] = u._pad[2] = 0; u.e = old;
-        L.e[L.ne++] = u;
+        uint32_t w[4]; __builtin_memcpy(w, &old, sizeof old);
+        uint32_t* r = L.eb + (size_t)L.ne * kUndoEWords * L.stride;
+        r[0] = eidx; TAFL_UNROLL for (uint32_t k = 0; k < 4; ++k) r[(k + 1u) * L.stride] = w[k];
+        L.ne += 1;
     }
     static TAFL_HD void log_hdr(SpecLog& L, uint32_t node, const NodeHdr& old) {
         if (L.nh >= L.cap) { L.ok = false; return; }
-        UndoH u; u.node = node; u._pad[0] = u._pad[1] = u._pad[2] = 0; u.h = old;
-        L.h[L.nh++] = u;
+        uint32_t w[8]; __builtin_memcpy(w, &old, sizeof old);
+        uint32_t* r = L.hb + (size_t)L.nh * kUndoHWords * L.stride;
+        r[0] = node; TAFL_UNROLL for (uint32_t k = 0; k < 8; ++k) r[(k + 1u) * L.stride] = w[k];
+        L.nh += 1;
     }
     // assumed backup: edge `eidx` of node `cur` receives v, then the path to the root as in mcts_backup; every touched record is logged.
     // new_edge: the edge was created by this pass (Qsa = 0, Nsa = 0, virtual child): nothing to fetch.
@@ -621,8 +627,8 @@ struct Ops {
     // Predicts the expansions of simulations first+1 .. first+want-1 after the real leaf `L` of simulation `first` became slot 0.
     // Returns the number of slots (placeholders included).  `assumed`: value assumed for a playout in flight, seen from the leaf's mover.
     static TAFL_HD uint32_t mcts_speculate(const MctsMem& M, uint32_t g, uint32_t leaf, uint32_t first, uint32_t want, double c_puct,
-                                           uint32_t n_sims, double assumed, const K& C, LaneStats& ls, StepCtx& X) {
-        SpecLog L; L.e = M.ulog_e + (size_t)g * M.ulog_cap; L.h = M.ulog_h + (size_t)g * M.ulog_cap; L.ne = L.nh = 0; L.cap = M.ulog_cap; L.ok = true;
+                                           uint32_t n_sims, double assumed, const K& C, LaneStats& ls, StepCtx& X, const LogMem& lm) {
+        SpecLog L; L.eb = lm.base + lm.lane; L.hb = lm.base + (size_t)lm.cap * kUndoEWords * lm.stride + lm.lane; L.stride = lm.stride; L.ne = L.nh = 0; L.cap = lm.cap; L.ok = true;
         const RootCache committed = X.rc;                          // the pass ends where it began
         uint32_t vtop = X.edge_top;                                // edge arrays that grow during the pass take free arena space, not committed
         uint32_t cnt = 1;
@@ -703,17 +709,18 @@ struct Ops {
             if (stop || !placed) break;
             cnt = t + 1;
         }
-        // restore the tree (reverse order: a record may have been logged more than once; the records are fetched four at a time, the
-        // stores keep their order)
-        for (uint32_t i = L.ne; i > 0; i -= (i < 4u ? i : 4u)) {
-            UndoE u[4];
-            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) u[t] = L.e[t < i ? i - 1u - t : 0u];
-            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) if (t < i) M.edges[(size_t)g * M.edge_cap + u[t].idx] = u[t].e;
+        // restore the tree (reverse order: a record may have been logged more than once)
+        for (uint32_t i = L.ne; i > 0; --i) {
+            const uint32_t* r = L.eb + (size_t)(i - 1u) * kUndoEWords * L.stride;
+            uint32_t w[4]; TAFL_UNROLL for (uint32_t k = 0; k < 4; ++k) w[k] = r[(k + 1u) * L.stride];
+            Edge e; __builtin_memcpy(&e, w, sizeof e);
+            M.edges[(size_t)g * M.edge_cap + r[0]] = e;
         }
-        for (uint32_t i = L.nh; i > 0; i -= (i < 4u ? i : 4u)) {
-            UndoH u[4];
-            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) u[t] = L.h[t < i ? i - 1u - t : 0u];
-            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) if (t < i) M.hdr[(size_t)u[t].node * M.G + g] = u[t].h;
+        for (uint32_t i = L.nh; i > 0; --i) {
+            const uint32_t* r = L.hb + (size_t)(i - 1u) * kUndoHWords * L.stride;
+            uint32_t w[8]; TAFL_UNROLL for (uint32_t k = 0; k < 8; ++k) w[k] = r[(k + 1u) * L.stride];
+            NodeHdr h; __builtin_memcpy(&h, w, sizeof h);
+            M.hdr[(size_t)r[0] * M.G + g] = h;
         }
         X.rc = committed;
         return cnt;
@@ -726,7 +733,7 @@ struct Ops {
     // lists: slot 0 (certain) first, the most speculative last.
     // wcap: most predicted simulations a game may run beside the pending one (the host lowers it while few predictions come true: a
     // prediction costs a child expansion in the tree phase whether it is consumed or not).
-    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, uint32_t wcap, const K& C, LaneStats& ls) {
+    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, uint32_t wcap, const K& C, LaneStats& ls, const LogMem& lm) {
         // everything the step needs from the per-game arrays, fetched side by side
         uint32_t sim = M.sim_next[g];
         const uint8_t kind0 = M.kind[g];
@@ -824,7 +831,7 @@ struct Ops {
             } else if (rounds_left == 0 && want > w + 1) want = w + 1;
             if (want > M.spec_k) want = M.spec_k;
             uint32_t cnt = 1;
-            if (want > 1 && sim + 1 < n_sims && M.ulog_cap > 0) cnt = mcts_speculate(M, g, L, sim, want, c_puct, n_sims, 0.0, C, ls, X);
+            if (want > 1 && sim + 1 < n_sims && lm.cap > 0) cnt = mcts_speculate(M, g, L, sim, want, c_puct, n_sims, 0.0, C, ls, X, lm);
             for (uint32_t t = cnt; t < M.spec_k; ++t) M.spec_kind[(size_t)t * M.G + g] = 0;
             M.spec_n[g] = (uint8_t)cnt; M.spec_first[g] = sim;
         }

@@ -16,6 +16,7 @@ using namespace tafl;
 static uint32_t g_spec_k = 4;          // playout slots per game that exist in the MCTS pipeline (1 = no speculation)
 static uint32_t g_spec_target = 0;     // slots per game and round the search is planned for (0: no plan, issue what is allowed)
 static uint32_t g_capacity = 0;        // playouts a round may run (0: all that are requested), like the device capacity of k_mcts_rollout
+static uint32_t g_log_cap = 16;        // undo records of each kind a prediction pass may write (the device's LDS holds 16 per lane; an overflow ends the pass early)
 static std::vector<uint32_t> g_round_work;   // playouts executed per round of the last hs_mcts call (cost-model experiments)
 static bool g_force_generic = false;   // differential tests: generic Engine::rollout vs the fast playout engine
 
@@ -80,26 +81,27 @@ struct Host {
         using IO = StateIO<NL>;
         // same host loop as tafl_mcts_run's two-kernel pipeline: g_spec_k slots exist per game, the search is planned for
         // ceil(n_sims / g_spec_target) rounds (g_spec_target = 0: every game issues as many slots as it may, every round)
-        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k; M.ulog_cap = g_spec_k > 1 ? 64 : 0; M.flags = p->flags & TAFL_MCTS_FLAG_FPU_INF;
+        MctsMem M; M.G = G; M.node_cap = p->n_sims + 1; M.edge_cap = 4 * (p->n_sims + 1); M.spec_k = g_spec_k; M.flags = p->flags & TAFL_MCTS_FLAG_FPU_INF;
         std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS), sst((size_t)M.spec_k * G * IO::QUADS);
         std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
         std::vector<Edge> edges((size_t)M.edge_cap * G);
         std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sfirst(G), splies((size_t)M.spec_k * G), smeta((size_t)M.spec_k * G), snode((size_t)M.spec_k * G), sord((size_t)M.spec_k * G);
         std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), sw(G);
         std::vector<int8_t> sval((size_t)M.spec_k * G);
-        std::vector<UndoE> ue((size_t)(M.ulog_cap ? M.ulog_cap : 1) * G); std::vector<UndoH> uh((size_t)(M.ulog_cap ? M.ulog_cap : 1) * G);
+        // the undo log of the prediction pass: one lane's scratch (the device keeps 64 of them side by side in LDS)
+        std::vector<uint32_t> logw((size_t)g_log_cap * (kUndoEWords + kUndoHWords) + 1);
+        LogMem lm; lm.base = logw.data(); lm.stride = 1; lm.lane = 0; lm.cap = g_spec_k > 1 ? g_log_cap : 0;
         M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
         M.leaf = leaf.data(); M.kind = kind.data(); M.fault = fault.data();
         M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data(); M.spec_meta = smeta.data();
         M.spec_plies = splies.data(); M.spec_node = snode.data(); M.spec_ord = sord.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_w = sw.data();
-        M.ulog_e = ue.data(); M.ulog_h = uh.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; load(st[g], s); O::mcts_init_game(M, g, s, C); }
         g_round_work.clear();
         auto tree = [&](uint32_t rounds_left) {
             for (uint32_t g = 0; g < G; ++g) {
                 LaneStats ls; memset(&ls, 0, sizeof ls);
-                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, rounds_left, g_spec_target, g_spec_k, C, ls);
+                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, rounds_left, g_spec_target, g_spec_k, C, ls, lm);
                 stats->sims += ls.sims; stats->tree_depth_sum += ls.depth; stats->children_scanned += ls.scanned;
                 stats->terminal_hits += ls.terminal_hits; stats->faults += ls.faults;
                 stats->rollouts += ls.rollouts; stats->rollout_plies += ls.rollout_plies;
@@ -218,6 +220,7 @@ void hs_force_generic(int on) { g_force_generic = on != 0; }
 void hs_set_spec_k(uint32_t k) { g_spec_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
 void hs_set_spec_target(uint32_t t) { g_spec_target = t > 8 ? 8 : t; }
 void hs_set_capacity(uint32_t c) { g_capacity = c; }
+void hs_set_log_cap(uint32_t c) { g_log_cap = c; }
 uint32_t hs_round_work(uint32_t* out, uint32_t cap) { const uint32_t n = (uint32_t)g_round_work.size(); for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = g_round_work[i]; return n; }
 int hs_movegen(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, uint32_t* counts, uint32_t* masks, uint32_t mw) { DISPATCH(movegen(r, n, st, cnt, counts, masks, mw)) }
 int hs_validate(const tafl_rules* r, uint8_t n, uint32_t word_bits, const tafl_state* st, uint32_t cnt, const tafl_play* plays, uint8_t* codes) { DISPATCH(validate(r, n, st, cnt, plays, codes)) }

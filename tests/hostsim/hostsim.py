@@ -49,6 +49,8 @@ def lib():
         L.hs_set_spec_target.argtypes = [C.c_uint32]
         L.hs_set_dense13.restype = None
         L.hs_set_dense13.argtypes = [C.c_int]
+        L.hs_set_log_cap.restype = None
+        L.hs_set_log_cap.argtypes = [C.c_uint32]
         L.hs_set_capacity.restype = None
         L.hs_set_capacity.argtypes = [C.c_uint32]
         L.hs_round_work.restype = C.c_uint32
@@ -117,6 +119,12 @@ class HostSim:
 def force_generic(on: bool):
     """Differential tests: make host-sim playouts use the generic Engine::rollout instead of the fast engine."""
     lib().hs_force_generic(int(on))
+
+
+def set_log_cap(cap: int):
+    """Undo records of each kind a prediction pass may write in host-sim MCTS runs (the device: 16 per lane in LDS, 5 in the fused kernel);
+    an overflow ends the pass early - fewer predictions, same results."""
+    lib().hs_set_log_cap(cap)
 
 
 def set_spec_k(k: int, target: int = 0, capacity: int = 0):

@@ -282,3 +282,31 @@ def test_mcts_first_play_urgency_flag(name, sims, k):
     assert differs
     for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
         assert getattr(ostats, f) == getattr(hstats, f), f
+
+
+@pytest.mark.parametrize("log_cap", [1, 2, 5, 16])
+def test_mcts_undo_log_overflow_only_ends_the_prediction_pass(log_cap):
+    """The prediction pass keeps its undo log in a small per-lane scratch (LDS on the device: 16 records of each kind, 5 in the fused
+    kernel).  A pass that runs out of records stops predicting and restores what it changed: fewer predictions, identical results."""
+    from tests.hostsim import hostsim
+    hostsim.set_spec_k(8, 4, 0)
+    hostsim.set_log_cap(log_cap)
+    try:
+        for name, G, sims, plies_cap in (("brandubh7", 12, 220, 80), ("copenhagen11", 6, 90, 60)):
+            rules, fen, wb, n, lg, hs = _mk(name)
+            states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+            plies = (C.c_uint32 * G)(*[(i * 7) % 30 for i in range(G)])
+            orc.batch_random_advance(lg, states, G, wb, 11, plies, 5)
+            p = TaflMctsParams(sims, plies_cap, 1.0, 17, 0, 0)
+            ok, on, ostats = orc.batch_mcts(lg, states, G, wb, p, 5)
+            hk, hn, hstats = hs.mcts(states, G, p, 5)
+            assert list(on) == list(hn)
+            for g in range(G):
+                for j in range(on[g]):
+                    a, b = ok[g * 256 + j], hk[g * 256 + j]
+                    assert (a.action, a.visits, float(a.q).hex()) == (b.action, b.visits, float(b.q).hex()), (name, log_cap, g, j)
+            for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+                assert getattr(ostats, f) == getattr(hstats, f), (name, f)
+    finally:
+        hostsim.set_spec_k(4, 0, 0)
+        hostsim.set_log_cap(16)
