@@ -222,7 +222,7 @@ struct Engine {
     static TAFL_HD bool canon_next(const S& st, uint32_t side, const K& C, Move& cur) {
         if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return false;
         const B occ = st.att | st.def;
-        const B mine = (side == 0 ? st.att : st.def) & C.board;
+        const B mine = sel(side == 0, st.att, st.def) & C.board;      // (sel: a `?:` between two objects becomes a pointer select + a trip through scratch memory)
         uint32_t sq = cur.from, dir = cur.dir, dist = cur.dist;
         if (sq == TAFL_NO_SQ) {                       // start: first piece of the side (iter_occupied order)
             if (!any(mine)) return false;
@@ -349,7 +349,7 @@ struct Engine {
         const B occ = st.att | st.def;
         const B empty = andn(C.board, occ);
         const int hcls = bcls == CLS_ATT ? CLS_DEF : CLS_ATT;                       // hostile soldier
-        B enemy = bcls == CLS_ATT ? st.def : st.att;
+        B enemy = sel(bcls == CLS_ATT, st.def, st.att);
         if (bcls == CLS_ATT && !king_armed_as_anvil(C)) enemy = andn(enemy, king_bit(st, C));
         const B th = (enemy & C.board) | (empty & C.hostile_special[bcls]);         // tile_hostile
         B safe = bz<NL>();
@@ -402,7 +402,7 @@ struct Engine {
     // ---- shieldwall (logic.rs:471-569): literal walk along the edge, rare --------------------------------------
     static TAFL_HD bool sw_search(const S& st, uint32_t to, bool horiz, int away, int dir, uint32_t mover, const K& C, B& wall) {
         const B occ = st.att | st.def;
-        const B mine = mover ? st.def : st.att, theirs = mover ? st.att : st.def;
+        const B mine = sel(mover != 0, st.def, st.att), theirs = sel(mover != 0, st.att, st.def);
         int r = (int)(to / (uint32_t)W), c = (int)(to % (uint32_t)W);
         wall = bz<NL>(); uint32_t n_wall = 0;
         for (int guard = 0; guard < 32; ++guard) {
@@ -616,7 +616,7 @@ struct Engine {
     static TAFL_HD Outcome outcome_early(const S& st, const ApplyCtx& ax, const K& C, bool skip_enclosure, bool skip_fort = false) {
         Outcome o; o.over = false; o.status = TAFL_STATUS_ONGOING; o.reason = 0; o.winner = 0;
         const uint32_t mover = ax.mover;
-        const B other = (mover ? st.att : st.def) & C.board;
+        const B other = sel(mover != 0, st.att, st.def) & C.board;
         if (!any(other)) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_ALL_CAPTURED; o.winner = mover; o.over = true; }
         if (!o.over && mover == 0) {
             if (ax.king_captured) { o.status = TAFL_STATUS_WIN; o.reason = TAFL_WIN_KING_CAPTURED; o.winner = 0; o.over = true; }

@@ -160,7 +160,7 @@ struct Fast {
 
     static TAFL_HD void gen(const S& st, const B& attT, const B& defT, uint32_t side, const K& C, const F& fc, Gen& g) {
         const B occN = (st.att | st.def) & C.board, occT = (attT | defT) & C.board;
-        const B mineN = (side ? st.def : st.att) & C.board, mineT = (side ? defT : attT) & C.board;
+        const B mineN = sel(side != 0, st.def, st.att) & C.board, mineT = sel(side != 0, defT, attT) & C.board;
         const uint32_t k = E::king_sq(st, C);
         B kN = bz<NL>(), kT = bz<NL>();
         // the king's own rays are needed only where a defender is to move (and only under rules that do not allow king_specials):

@@ -89,14 +89,24 @@ struct Guided {
     }
     static TAFL_HD double np_sum_sparse(const GEdge* e, uint32_t cnt, uint32_t A, bool add1) {
         struct Frame { uint32_t lo, n; uint32_t stage; double left; };
-        Frame stk[16]; int sp = 0; uint32_t cur = 0; double ret = 0.;
-        stk[sp].lo = 0; stk[sp].n = A; stk[sp].stage = 0; stk[sp].left = 0.; ++sp;
+        // the recursion's frames: a per-lane stack indexed at run time.  In registers that is scratch memory (it was 400 of this kernel's
+        // 496 B per lane); on the device it lives in LDS, one column per lane of the 64-thread workgroup
+#if defined(__HIP_DEVICE_COMPILE__)
+        __shared__ Frame stk_lds[16 * 64];
+        Frame* const stk = stk_lds + (threadIdx.x & 63u);
+        constexpr int SS = 64;
+#else
+        Frame stk_host[16]; Frame* const stk = stk_host;
+        constexpr int SS = 1;
+#endif
+        int sp = 0; uint32_t cur = 0; double ret = 0.;
+        stk[sp * SS].lo = 0; stk[sp * SS].n = A; stk[sp * SS].stage = 0; stk[sp * SS].left = 0.; ++sp;
         while (sp > 0) {
-            Frame& f = stk[sp - 1];
+            Frame& f = stk[(sp - 1) * SS];
             if (f.n <= 128u) { ret = leaf_sum(e, cnt, cur, f.lo, f.n, add1); --sp; continue; }
             uint32_t n2 = f.n / 2u; n2 -= n2 % 8u;
-            if (f.stage == 0) { f.stage = 1; stk[sp].lo = f.lo; stk[sp].n = n2; stk[sp].stage = 0; stk[sp].left = 0.; ++sp; }
-            else if (f.stage == 1) { f.left = ret; f.stage = 2; stk[sp].lo = f.lo + n2; stk[sp].n = f.n - n2; stk[sp].stage = 0; stk[sp].left = 0.; ++sp; }
+            if (f.stage == 0) { f.stage = 1; Frame& c = stk[sp * SS]; c.lo = f.lo; c.n = n2; c.stage = 0; c.left = 0.; ++sp; }
+            else if (f.stage == 1) { f.left = ret; f.stage = 2; Frame& c = stk[sp * SS]; c.lo = f.lo + n2; c.n = f.n - n2; c.stage = 0; c.left = 0.; ++sp; }
             else { ret = f.left + ret; --sp; }
         }
         return 0.0 + ret;                                       // np.add.reduce: identity + pairwise sum

@@ -199,7 +199,7 @@ struct Ops {
         constexpr uint32_t i = (uint32_t)I, base = (uint32_t)(I * W);
         if (TAFL_F_STATUS(st.flags) != TAFL_STATUS_ONGOING) return 0;                   // logic.rs:165-167
         const uint32_t side = st.flags & TAFL_F_SIDE, n = C.n, nm = n - 1u;
-        const Bits<NL> occ = (st.att | st.def) & C.board, mine = (side ? st.def : st.att) & C.board;
+        const Bits<NL> occ = (st.att | st.def) & C.board, mine = sel(side != 0, st.def, st.att) & C.board;
         const int scls = side ? CLS_DEF : CLS_ATT;
         // rule masks of line I for the soldiers of the side and for the king (column I of them = row I: the sets equal their mirror image)
         const uint32_t s_lf = line_bits(C.land_forbid[scls], base, n), s_pf = line_bits(C.pass_forbid[scls], base, n);
@@ -468,10 +468,13 @@ struct Ops {
                 } else {
                     // eight independent loads in flight per step (one load and one wait per edge made this scan the longest dependent
                     // chain of the tree phase: every wait is a trip to L2 / HBM)
-                    for (uint32_t t0 = 0; t0 < lim; t0 += 8) {
-                        double q[8];
-                        TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) q[t] = eb[j0 + (t0 + t < lim ? t0 + t : lim - 1u)].q;
-                        TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) pos |= ((t0 + t < lim && q[t] > 0.0) ? 1u : 0u) << (t0 + t);
+                    for (uint32_t t0 = 0; t0 < lim; t0 += 8) {       // (named values, not an array: the array went to scratch memory)
+#define TAFL_QLOAD(t) const double q##t = eb[j0 + (t0 + t < lim ? t0 + t : lim - 1u)].q
+#define TAFL_QBIT(t) (((t0 + t < lim && q##t > 0.0) ? 1u : 0u) << (t0 + t))
+                        TAFL_QLOAD(0u); TAFL_QLOAD(1u); TAFL_QLOAD(2u); TAFL_QLOAD(3u); TAFL_QLOAD(4u); TAFL_QLOAD(5u); TAFL_QLOAD(6u); TAFL_QLOAD(7u);
+                        pos |= TAFL_QBIT(0u) | TAFL_QBIT(1u) | TAFL_QBIT(2u) | TAFL_QBIT(3u) | TAFL_QBIT(4u) | TAFL_QBIT(5u) | TAFL_QBIT(6u) | TAFL_QBIT(7u);
+#undef TAFL_QLOAD
+#undef TAFL_QBIT
                     }
                     if (cacheable) { const uint32_t wi = j0 >> 5; TAFL_UNROLL for (uint32_t i = 0; i < 4; ++i) seen[i] = i == wi ? pos : seen[i]; }
                 }
@@ -487,12 +490,13 @@ struct Ops {
             if (u0 > cur_best) { cur_best = u0; best = (int)h.m; }
             return best;
         }
-        // the edge records are fetched eight at a time (independent loads in flight: this loop is bound by memory latency),
+        // the edge records are fetched four at a time (independent loads in flight: this loop is bound by memory latency; eight at a time
+        // cost the tree kernel 32 VGPRs it does not have: it spilled),
         // then evaluated in ascending order as mcts.py does
-        for (uint32_t j0 = 0; j0 < h.m; j0 += 8) {
-            Edge e[8];
-            TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) e[t] = eb[(j0 + t < h.m) ? j0 + t : j0];
-            TAFL_UNROLL for (uint32_t t = 0; t < 8; ++t) {
+        for (uint32_t j0 = 0; j0 < h.m; j0 += 4) {
+            Edge e[4];
+            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) e[t] = eb[(j0 + t < h.m) ? j0 + t : j0];
+            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) {
                 const double u = e[t].q + cp * sq / (double)(1 + e[t].n);
                 if (j0 + t < h.m && u > cur_best) { cur_best = u; best = (int)(j0 + t); }
             }
@@ -507,10 +511,12 @@ struct Ops {
     // edge array of a node moved to a larger allocation: four records in flight (a load, a wait and a store per record is one memory
     // round trip per record, and the whole wave waits for the game with the longest array)
     static TAFL_HD void copy_edges(Edge* dst, const Edge* src, uint32_t n) {
-        for (uint32_t j = 0; j < n; j += 4) {
-            Edge t4[4];
-            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) t4[t] = src[j + t < n ? j + t : n - 1u];
-            TAFL_UNROLL for (uint32_t t = 0; t < 4; ++t) if (j + t < n) dst[j + t] = t4[t];
+        for (uint32_t j = 0; j < n; j += 4) {          // (named values: an array of four records behind conditional stores cost 16 B more scratch)
+            const Edge e0 = src[j], e1 = src[j + 1 < n ? j + 1 : n - 1u], e2 = src[j + 2 < n ? j + 2 : n - 1u], e3 = src[j + 3 < n ? j + 3 : n - 1u];
+            dst[j] = e0;
+            if (j + 1 < n) dst[j + 1] = e1;
+            if (j + 2 < n) dst[j + 2] = e2;
+            if (j + 3 < n) dst[j + 3] = e3;
         }
     }
 
@@ -629,7 +635,6 @@ struct Ops {
     static TAFL_HD uint32_t mcts_speculate(const MctsMem& M, uint32_t g, uint32_t leaf, uint32_t first, uint32_t want, double c_puct,
                                            uint32_t n_sims, double assumed, const K& C, LaneStats& ls, StepCtx& X, const LogMem& lm) {
         SpecLog L; L.eb = lm.base + lm.lane; L.hb = lm.base + (size_t)lm.cap * kUndoEWords * lm.stride + lm.lane; L.stride = lm.stride; L.ne = L.nh = 0; L.cap = lm.cap; L.ok = true;
-        const RootCache committed = X.rc;                          // the pass ends where it began
         uint32_t vtop = X.edge_top;                                // edge arrays that grow during the pass take free arena space, not committed
         uint32_t cnt = 1;
         // the pending leaf as it will be once its playout value arrives: expanded, its path updated with the assumed value
@@ -722,7 +727,7 @@ struct Ops {
             NodeHdr h; __builtin_memcpy(&h, w, sizeof h);
             M.hdr[(size_t)r[0] * M.G + g] = h;
         }
-        X.rc = committed;
+        // (the step's register copy of the root - X.rc - still shows the pass's last state: the pass is the last thing a step does with it)
         return cnt;
     }
 
