@@ -48,6 +48,7 @@ SYMBOLS = [
     ("tafl_mcts_run_async", _i32, [_vp, _P(TaflMctsParams), _u64]),
     ("tafl_mcts_run_async_after", _i32, [_vp, _P(TaflMctsParams), _u64, _vp]),
     ("tafl_mcts_wait", _i32, [_vp]),
+    ("tafl_selfplay_run", _i32, [_vp, _P(TaflMctsParams), _u32, _u64, _P(TaflPlay)]),
     ("tafl_mcts_get_stats", _i32, [_vp, _P(TaflMctsStats)]),
     ("tafl_mcts_root_children", _i32, [_vp, _P(TaflRootChild), _u32, _P(_u32)]),
     ("tafl_mcts_root_visits", _i32, [_vp, _P(_u32)]),

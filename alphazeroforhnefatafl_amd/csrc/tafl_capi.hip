@@ -283,10 +283,12 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_init(Consts<NL> C, const Qu
 
 // tree phase of the simulation pipeline: consume finished playouts (backup), run as many further simulations as can be
 // served by ready slots, then issue the next slots (tafl_ops.hpp mcts_tree_step)
-template <int NL, int W, int PRESET>
-__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, uint32_t round, uint32_t planned, uint32_t probe_every,
-                                                          uint32_t target, unsigned long long* stats, const unsigned long long* ctrl, uint32_t* work, uint32_t* work_count,
-                                                          uint32_t g_begin, uint32_t g_end) {
+// SP: a self-play run (tafl_selfplay_run): a game whose search is done plays its most visited root play on the batch state (soa, layout
+// <NLS, WS>) and starts its next search in the same launch; its plan counts from the launch in which that search began
+template <int NLS, int WS, int NL, int W, int PRESET, bool SP>
+__device__ __forceinline__ void mcts_tree_launch(const Consts<NL>& Carg, const MctsMem& M, double c_puct, uint32_t n_sims, uint32_t round, uint32_t planned, uint32_t probe_every,
+                                                 uint32_t target, unsigned long long* stats, const unsigned long long* ctrl, uint32_t* work, uint32_t* work_count,
+                                                 uint32_t g_begin, uint32_t g_end, Quad* soa, const SelfPlay& sp) {
     const uint32_t g = g_begin + blockIdx.x * TAFL_BLOCK + threadIdx.x;     // this launch serves games g_begin .. g_end - 1
     // the tree phase of one half of the batch runs beside the other half's playouts (2 - 4 waves per SIMD): it is one latency-bound wave
     // per SIMD on the critical path of its half, so its instructions go first
@@ -294,21 +296,33 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
     TAFL_PICK_CONSTS(C, Carg);
     LaneStats ls; ls.sims = ls.rollouts = ls.rollout_plies = ls.depth = ls.scanned = ls.terminal_hits = ls.faults = ls.reason = 0;
     ls.reason_hist4 = 0; ls.spec_issued = ls.spec_hits = 0;
-    const bool live = g < g_end && (M.sim_next[g] < n_sims || M.kind[g] == 1);
-    if (__ballot(live) == 0ull) return;                       // whole wave finished: nothing to do, nothing to count
+    bool live = g < g_end && (M.sim_next[g] < n_sims || M.kind[g] == 1);
+    if constexpr (SP) {
+        const bool adv = g < g_end && !live && sp.moves_done[g] < sp.n_moves;
+        if (__ballot(live || adv) == 0ull) return;
+        int r = 0;
+        if (adv) r = Ops<NL, W>::template selfplay_advance<NLS, WS>(M, g, soa, sp, n_sims, round, C);
+        live = live || r == 1;                                // the new search takes its first step in this launch
+        const unsigned long long fin = __ballot(r == 2);      // games that made their last play
+        if ((threadIdx.x & 63u) == 0 && fin) atomicAdd(&stats[ST_DONE], (unsigned long long)__popcll(fin));
+    } else {
+        (void)soa; (void)sp;
+        if (__ballot(live) == 0ull) return;                   // whole wave finished: nothing to do, nothing to count
+    }
     // Plan (wave-uniform): inside the plan a game issues ceil(remaining / rounds left) slots.  Past it: 1 = "use every slot that exists"
     // (wasted playouts are free on an emptying device) for short searches and, for long ones, once three quarters of the games are done;
     // until then 0 = every game keeps to what its own hit history allows (a long search whose predictions fail runs far beyond the plan
     // with every game still alive: S = 1000 runs 44 M sims/s this way, 39 M otherwise).  Both only steer WHEN playouts run, never a result.
     uint32_t rounds_left;
-    if (round < planned) rounds_left = planned - round;
+    if constexpr (SP) { const uint32_t rel = live ? round - sp.start_round[g] : 0u; rounds_left = rel < planned ? planned - rel : 1u; }      // per game
+    else if (round < planned) rounds_left = planned - round;
     else rounds_left = (probe_every == 0u || 4ull * ld_counter(&stats[ST_DONE]) >= 3ull * (unsigned long long)M.G) ? 1u : 0u;
     const uint32_t wcap = (uint32_t)ld_counter(&ctrl[CT_WCAP]);
     // the undo log of the prediction pass: LDS, one log per lane, word-interleaved (tafl_ops.hpp LogMem)
     extern __shared__ uint32_t tree_lds[];
     LogMem lm; lm.base = tree_lds; lm.stride = TAFL_BLOCK; lm.lane = threadIdx.x & 63u; lm.cap = TAFL_MCTS_UNDO_CAP;
     if (live) Ops<NL, W>::mcts_tree_step(M, g, c_puct, n_sims, rounds_left, target, wcap, C, ls, lm);
-    {   // games that completed their last simulation in this launch (a finished game is never live again: counted once)
+    if constexpr (!SP) {   // games that completed their last simulation in this launch (a finished game is never live again: counted once)
         const unsigned long long fin = __ballot(live && M.sim_next[g] >= n_sims && M.kind[g] != 1);
         if ((threadIdx.x & 63u) == 0 && fin) atomicAdd(&stats[ST_DONE], (unsigned long long)__popcll(fin));
     }
@@ -337,6 +351,19 @@ __global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsM
     stat_add(stats, ST_ROLLOUTS, ls.rollouts); stat_add(stats, ST_PLIES, ls.rollout_plies);
     stat_add(stats, ST_SPEC_ISSUED, ls.spec_issued); stat_add(stats, ST_SPEC_HITS, ls.spec_hits);
     for (uint32_t r = 0; r < 16; ++r) stat_add(stats, ST_REASON0 + r, (uint32_t)((ls.reason_hist4 >> (4u * r)) & 15ull));
+}
+template <int NL, int W, int PRESET>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, uint32_t round, uint32_t planned, uint32_t probe_every,
+                                                          uint32_t target, unsigned long long* stats, const unsigned long long* ctrl, uint32_t* work, uint32_t* work_count,
+                                                          uint32_t g_begin, uint32_t g_end) {
+    SelfPlay none; none.moves_done = nullptr; none.start_round = nullptr; none.plays = nullptr; none.n_moves = 0;
+    mcts_tree_launch<NL, W, NL, W, PRESET, false>(Carg, M, c_puct, n_sims, round, planned, probe_every, target, stats, ctrl, work, work_count, g_begin, g_end, nullptr, none);
+}
+template <int NLS, int WS, int NL, int W, int PRESET>
+__global__ __launch_bounds__(TAFL_BLOCK) void k_mcts_tree_selfplay(Consts<NL> Carg, MctsMem M, double c_puct, uint32_t n_sims, uint32_t round, uint32_t planned, uint32_t probe_every,
+                                                                   uint32_t target, unsigned long long* stats, const unsigned long long* ctrl, uint32_t* work, uint32_t* work_count,
+                                                                   uint32_t g_begin, uint32_t g_end, Quad* soa, SelfPlay sp) {
+    mcts_tree_launch<NLS, WS, NL, W, PRESET, true>(Carg, M, c_puct, n_sims, round, planned, probe_every, target, stats, ctrl, work, work_count, g_begin, g_end, soa, sp);
 }
 
 // the dominant kernel: one seeded random playout per entry of the round's work list (slot, game), state resident in registers.
@@ -618,6 +645,7 @@ struct SearchPlan {
     MctsMem M;
     uint32_t parts, slots, planned, probe_every, next_round, max_rounds;
     unsigned long long ctrl0[4];     // initial control words (CT_*): source of an asynchronous copy
+    SelfPlay selfplay;               // n_moves != 0: a self-play run (tafl_selfplay_run)
     SearchPart P[TAFL_MCTS_MAX_PARTS];
 };
 
@@ -638,11 +666,12 @@ struct tafl_batch {
     MctsMem mem; bool has_mem; uint32_t reserved_sims;
     DevBuf node_state, hdr, edges, node_top, edge_top, leaf, kind, fault, stats, children, children_n, visits;
     DevBuf best_plays, best_visits, enc, policy;
-    DevBuf work, work_count, trace;
+    DevBuf work, work_count, trace, sim_base, sp_moves_done, sp_start_round, sp_plays;
     uint32_t trace_rounds;           // rounds of the last two-kernel search recorded in `trace` (requested / run playouts per round)
     DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_node, spec_ord, spec_first, spec_n, spec_w;
     uint32_t spec_k;                 // playout slots per game that exist (TAFL_MCTS_MAX_SLOTS)
     tafl_mcts_stats last_stats; bool ran;
+    bool stats_ok;                   // the counters of the last finished search / self-play run can be read (a self-play run leaves no tree: ran = false)
     // guided MCTS (external evaluator)
     GuidedMem gmem; bool g_has; uint32_t g_max_sims;
     DevBuf g_node_state, g_hdr, g_pedge, g_edges, g_node_top, g_edge_top, g_leaf, g_kind, g_fault, g_sims, g_stats, g_priors, g_values, g_boards, g_sides, g_wait;
@@ -829,7 +858,7 @@ int tafl_batch_create(tafl_ctx* c, uint32_t n, tafl_batch** out) {
 #else
     b->spec_k = TAFL_MCTS_MAX_SLOTS;
 #endif
-    b->n_sstreams = 0; b->half_recorded = false;
+    b->n_sstreams = 0; b->half_recorded = false; b->stats_ok = false;
     memset(&b->mem, 0, sizeof b->mem); memset(&b->last_stats, 0, sizeof b->last_stats); memset(&b->plan, 0, sizeof b->plan);
     const size_t bytes = (size_t)quads_of(c) * n * sizeof(Quad);
     if (hipMalloc((void**)&b->soa, bytes) != hipSuccess) { delete b; return fail(TAFL_ERR_OOM, "hipMalloc(batch states) failed"); }
@@ -852,7 +881,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_meta, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl,
+                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl, &b->sim_base, &b->sp_moves_done, &b->sp_start_round, &b->sp_plays,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
                       &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
     for (DevBuf* d : bufs) d->release();
@@ -1062,11 +1091,11 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * arena_quads(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
     NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_node, k * n * 4); NEED(b->spec_ord, k * n * 4); NEED(b->spec_first, n * 4);
     NEED(b->spec_n, n); NEED(b->spec_w, n); NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
-    NEED(b->ctrl, sizeof(unsigned long long) * CT_COUNT);
+    NEED(b->ctrl, sizeof(unsigned long long) * CT_COUNT); NEED(b->sim_base, n * 4);
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
     b->mem.kind = (uint8_t*)b->kind.p; b->mem.fault = (uint8_t*)b->fault.p;
-    b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p; b->mem.spec_meta = (uint32_t*)b->spec_meta.p;
+    b->mem.sim_base = (uint32_t*)b->sim_base.p; b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p; b->mem.spec_meta = (uint32_t*)b->spec_meta.p;
     b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
     b->mem.spec_node = (uint32_t*)b->spec_node.p; b->mem.spec_ord = (uint32_t*)b->spec_ord.p; b->mem.spec_first = (uint32_t*)b->spec_first.p;
     b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_w = (uint8_t*)b->spec_w.p; b->mem.spec_k = b->spec_k;
@@ -1110,8 +1139,12 @@ static int mcts_enqueue_rounds(tafl_batch* b, uint32_t count, bool stagger) {
             uint32_t* wc_now = pk.wc + (i & 1u) * TAFL_MCTS_MAX_SLOTS; uint32_t* wc_next = pk.wc + ((i + 1u) & 1u) * TAFL_MCTS_MAX_SLOTS;
             {
                 SpanGuard sg(c, KC_MCTS_TREE, pk.s);
-                DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), TAFL_UNDO_LDS_BYTES(TAFL_MCTS_UNDO_CAP), pk.s, CC, M, p->c_puct, p->n_sims, i, sp.planned, sp.probe_every,
-                                                      sp.slots, st, ctrl, pk.wl, wc_now, pk.g0, pk.g1));
+                if (sp.selfplay.n_moves)
+                    DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_tree_selfplay<NLS, WS, NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), TAFL_UNDO_LDS_BYTES(TAFL_MCTS_UNDO_CAP), pk.s, CC, M, p->c_puct, p->n_sims, i, sp.planned, sp.probe_every,
+                                                          sp.slots, st, ctrl, pk.wl, wc_now, pk.g0, pk.g1, b->soa, sp.selfplay));
+                else
+                    DISPATCH_ARENA_PRESET(c, hipLaunchKernelGGL((k_mcts_tree<NL, W, PRESET>), dim3(pk.grid_tree), dim3(TAFL_BLOCK), TAFL_UNDO_LDS_BYTES(TAFL_MCTS_UNDO_CAP), pk.s, CC, M, p->c_puct, p->n_sims, i, sp.planned, sp.probe_every,
+                                                          sp.slots, st, ctrl, pk.wl, wc_now, pk.g0, pk.g1));
             }
             // partition k+1 starts behind partition k's first tree launch: from then on the tree phases are spread over a round
             if (stagger && k + 1 < sp.parts) {
@@ -1153,7 +1186,7 @@ static int mcts_enqueue_fused(tafl_batch* b, uint32_t rounds) {
 
 int tafl_mcts_wait(tafl_batch* b);
 
-static int mcts_begin(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base, tafl_batch* after) {
+static int mcts_begin(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base, tafl_batch* after, uint32_t n_moves = 0) {
     if (!b || !p) return fail(TAFL_ERR_INVALID_ARG, "null argument");
     if (p->flags & ~(uint32_t)TAFL_MCTS_FLAGS_KNOWN) return fail(TAFL_ERR_UNSUPPORTED, "tafl_mcts_params.flags: unknown bits set");
     if (p->n_sims == 0) return fail(TAFL_ERR_INVALID_ARG, "n_sims must be > 0");
@@ -1165,6 +1198,7 @@ static int mcts_begin(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id
     HIPCHK(hipSetDevice(c->device));
     SearchPlan& sp = b->plan;
     sp.p = *p; sp.base = game_id_base; sp.next_round = 0; sp.fused = false;
+    sp.selfplay.n_moves = n_moves; sp.selfplay.moves_done = nullptr; sp.selfplay.start_round = nullptr; sp.selfplay.plays = nullptr;
     MctsMem& M = sp.M; M = b->mem;
     M.node_cap = p->n_sims + 1; M.edge_cap = b->mem.edge_cap; M.flags = p->flags & TAFL_MCTS_FLAG_FPU_INF;
     // tuning fields of `flags` (results never depend on them): pipeline and playout slots per game
@@ -1176,7 +1210,8 @@ static int mcts_begin(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id
     // The fused kernel is built for 64-bit boards only (7x7): on wider boards its tree phase does not fit the register file beside the
     // playout loop (256 VGPRs and spills) and the two-kernel pipeline is faster anyway (13x13: 44.9 M vs 37.4 M sims/s).
     if (pipe == TAFL_MCTS_PIPELINE_FUSED && c->nl != 2) return fail(TAFL_ERR_UNSUPPORTED, "the fused pipeline exists for 64-bit boards (word_bits 64) only");
-    const bool fused = pipe == TAFL_MCTS_PIPELINE_FUSED || (pipe == TAFL_MCTS_PIPELINE_DEFAULT && c->nl == 2 && slots <= 2);
+    if (n_moves && pipe == TAFL_MCTS_PIPELINE_FUSED) return fail(TAFL_ERR_UNSUPPORTED, "tafl_selfplay_run uses the two-kernel pipeline");
+    const bool fused = !n_moves && (pipe == TAFL_MCTS_PIPELINE_FUSED || (pipe == TAFL_MCTS_PIPELINE_DEFAULT && c->nl == 2 && slots <= 2));
     if (fused && slots == 0) slots = 2;
     if (fused && slots > 2) return fail(TAFL_ERR_UNSUPPORTED, "the fused pipeline has 1 or 2 playout slots per game");
     uint32_t capacity = 0;
@@ -1273,6 +1308,17 @@ static int mcts_begin(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id
     HIPCHK(hipMemsetAsync(b->trace.p, 0, 8 * TAFL_MCTS_TRACE_ROUNDS, s0));
     HIPCHK(hipMemsetAsync(wcount, 0, sizeof(uint32_t) * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS, s0));
     uint32_t first = planned + tail_guess;
+    if (n_moves) {
+        // a self-play run: n_moves searches per game, each game at its own pace (k_mcts_tree_selfplay); most games need planned + 0..1 rounds per search
+        NEED(b->sp_moves_done, sizeof(uint32_t) * (size_t)n); NEED(b->sp_start_round, sizeof(uint32_t) * (size_t)n); NEED(b->sp_plays, sizeof(tafl_play) * (size_t)n * n_moves);
+        sp.selfplay.moves_done = (uint32_t*)b->sp_moves_done.p; sp.selfplay.start_round = (uint32_t*)b->sp_start_round.p; sp.selfplay.plays = (tafl_play*)b->sp_plays.p;
+        HIPCHK(hipMemsetAsync(b->sp_moves_done.p, 0, sizeof(uint32_t) * (size_t)n, s0)); HIPCHK(hipMemsetAsync(b->sp_start_round.p, 0, sizeof(uint32_t) * (size_t)n, s0));
+        HIPCHK(hipMemsetAsync(b->sp_plays.p, 0, sizeof(tafl_play) * (size_t)n * n_moves, s0));
+        const unsigned long long all = (unsigned long long)sp.max_rounds * n_moves;
+        sp.max_rounds = all > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)all;
+        const unsigned long long want = (unsigned long long)(planned + 1u) * n_moves + tail_guess;
+        first = want > sp.max_rounds ? sp.max_rounds : (uint32_t)want;
+    }
     if (first > sp.max_rounds) first = sp.max_rounds;
     if ((rc = mcts_enqueue_rounds(b, first, parts > 1)) != TAFL_OK) return rc;
     sp.active = true;
@@ -1300,13 +1346,30 @@ int tafl_mcts_wait(tafl_batch* b) {
         const int rc = mcts_enqueue_rounds(b, sp.planned >= 32 ? 4u : 2u, false);
         if (rc) return rc;
     }
-    b->ran = true;
+    b->ran = true; b->stats_ok = true;
     return TAFL_OK;
 }
 
 int tafl_mcts_run(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id_base) {
     const int rc = mcts_begin(b, p, game_id_base, nullptr);
     return rc ? rc : tafl_mcts_wait(b);
+}
+
+// n_moves x { tafl_mcts_run with sim_offset + move * n_sims; tafl_mcts_play_best } for every game, without leaving the device and without a
+// barrier between the moves: a game starts its next search as soon as its own is done (SelfPlay, tafl_ops.hpp)
+int tafl_selfplay_run(tafl_batch* b, const tafl_mcts_params* p, uint32_t n_moves, uint64_t game_id_base, tafl_play* out_plays) {
+    if (!b || !p || n_moves == 0) return fail(TAFL_ERR_INVALID_ARG, "tafl_selfplay_run: bad argument");
+    if ((unsigned long long)n_moves * p->n_sims + p->sim_offset > 0xFFFFFFFFull) return fail(TAFL_ERR_INVALID_ARG, "tafl_selfplay_run: sim_offset + n_moves * n_sims exceeds 32 bits");
+    int rc = mcts_begin(b, p, game_id_base, nullptr, n_moves);
+    if (rc == TAFL_OK) rc = tafl_mcts_wait(b);
+    b->ran = false;                                          // the trees belong to roots that have been played away from
+    if (rc) return rc;
+    if (out_plays) {
+        tafl_ctx* c = b->ctx;
+        HIPCHK(hipMemcpyAsync(out_plays, b->sp_plays.p, sizeof(tafl_play) * (size_t)b->n * n_moves, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return TAFL_OK;
 }
 
 // every reader of a search's results joins a search in flight first; non-zero = there is no finished search to read
@@ -1317,7 +1380,9 @@ static int search_done(tafl_batch* b) {
 
 // measurement: playouts requested / run in every round of the last two-kernel search (0 rounds after a fused search)
 int tafl_mcts_round_trace(tafl_batch* b, uint32_t* requested, uint32_t* run, uint32_t cap, uint32_t* n_rounds) {
-    if (!b || !n_rounds || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "bad argument / no MCTS run");
+    if (!b || !n_rounds) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    if (b->plan.active && tafl_mcts_wait(b) != TAFL_OK) return TAFL_ERR_HIP;
+    if (!b->stats_ok) return fail(TAFL_ERR_INVALID_ARG, "no MCTS run on this batch");
     tafl_ctx* c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     const uint32_t k = b->trace_rounds < TAFL_MCTS_TRACE_ROUNDS ? b->trace_rounds : TAFL_MCTS_TRACE_ROUNDS;
@@ -1329,7 +1394,9 @@ int tafl_mcts_round_trace(tafl_batch* b, uint32_t* requested, uint32_t* run, uin
 }
 
 int tafl_mcts_get_stats(tafl_batch* b, tafl_mcts_stats* out) {
-    if (!b || !out || search_done(b)) return fail(TAFL_ERR_INVALID_ARG, "no MCTS run on this batch");
+    if (!b || !out) return fail(TAFL_ERR_INVALID_ARG, "null argument");
+    if (b->plan.active && tafl_mcts_wait(b) != TAFL_OK) return TAFL_ERR_HIP;
+    if (!b->stats_ok) return fail(TAFL_ERR_INVALID_ARG, "no MCTS run on this batch");
     tafl_ctx* c = b->ctx;
     HIPCHK(hipSetDevice(c->device));
     unsigned long long h[ST_COUNT];

@@ -88,6 +88,7 @@ struct MctsMem {
     // ---- simulation pipeline (DESIGN.md "speculative playout slots") ------------------------------------------
     // Slot j of game g is the playout keyed by simulation index spec_first[g] + j.  Slot 0 is the leaf of the pending real
     // simulation; slots 1.. are PREDICTED expansions: child `spec_ord` of node `spec_node`.
+    uint32_t* sim_base;          // [G] added to the simulation index in the RNG key: 0 for a plain search, move * n_sims in a self-play run
     uint32_t* sim_next;          // [G] simulations completed so far
     Quad* spec_state;            // [(j * G + g) * QUADS] leaf state of slot j
     int8_t* spec_value;          // [j * G + g] playout value of slot j
@@ -104,6 +105,17 @@ struct MctsMem {
                                  //     what was consumed + 1 after a misprediction)
     uint32_t G, node_cap, edge_cap, spec_k;      // spec_k: slots per game that exist (capacity of the arrays above)
     uint32_t flags;              // TAFL_MCTS_FLAG_* semantics bits of the running search
+};
+
+// Self-play run (tafl_selfplay_run): every game runs n_moves searches one after the other, each followed by its most visited root play on
+// the batch state; a game starts its next search as soon as ITS OWN search is done, so the games of a batch are at different phases of
+// their searches and every launch finds the device full (a batch of synchronous searches ends each of them in a tail of nearly empty
+// rounds: DESIGN.md section 6).  Per game identical to the loop { tafl_mcts_run(sim_offset + move * n_sims); tafl_mcts_play_best }.
+struct SelfPlay {
+    uint32_t* moves_done;        // [G] searches + plays completed (n_moves: the game takes no further part)
+    uint32_t* start_round;       // [G] launch index at which the game's current search began (its plan counts from there)
+    tafl_play* plays;            // [n_moves * G] the plays made (all-zero play: the game was over)
+    uint32_t n_moves;
 };
 
 struct LaneStats {
@@ -345,7 +357,7 @@ struct Ops {
         M.hdr[g] = h;
         IO::store_rec(M.node_state + (size_t)g * IO::QUADS, root);
         M.node_top[g] = 1; M.edge_top[g] = 0; M.leaf[g] = 0; M.kind[g] = 0; M.fault[g] = 0;
-        M.sim_next[g] = 0; M.spec_n[g] = 0; M.spec_first[g] = 0; M.spec_w[g] = (uint8_t)(M.spec_k > 0 ? M.spec_k - 1 : 0);
+        M.sim_next[g] = 0; M.sim_base[g] = 0; M.spec_n[g] = 0; M.spec_first[g] = 0; M.spec_w[g] = (uint8_t)(M.spec_k > 0 ? M.spec_k - 1 : 0);
         for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;
     }
 
@@ -851,8 +863,44 @@ struct Ops {
         if (j >= M.spec_n[g] || M.spec_kind[o] != 1) return;
         S st; IO::load_rec(M.spec_state + o * IO::QUADS, st);
         tafl_rollout_result r;
-        playout(st, E::sim_key(E::game_key(seed, game_id), sim_offset + M.spec_first[g] + j), max_plies, C, r);
+        playout(st, E::sim_key(E::game_key(seed, game_id), sim_offset + M.sim_base[g] + M.spec_first[g] + j), max_plies, C, r);
         M.spec_value[o] = r.value; M.spec_reason[o] = r.reason; M.spec_plies[o] = r.plies; M.spec_kind[o] = 2;
+    }
+
+    // Self-play: if game g has finished its search, play the most visited root play (first maximum, src/mcts.rs:216-227, = tafl_mcts_play_best)
+    // on its batch state and start its next search.  The batch holds the position in the reference layout <NLS, WS>, the search arena in
+    // <NL, W> (the same, or the dense 13-column layout).  Returns 0 nothing to do, 1 a new search begins, 2 the game has made its last play.
+    template <int NLS, int WS>
+    static TAFL_HD int selfplay_advance(const MctsMem& M, uint32_t g, Quad* soa, const SelfPlay& sp, uint32_t n_sims, uint32_t round, const K& C) {
+        const uint32_t md = sp.moves_done[g];
+        if (md >= sp.n_moves) return 0;
+        if (M.sim_next[g] < n_sims || M.kind[g] == 1) return 0;              // its search is still running
+        const NodeHdr h = M.hdr[g];
+        const Edge* eb = &M.edges[(size_t)g * M.edge_cap + h.edge_base];
+        uint32_t best = 0, child = 0;
+        for (uint32_t j = 0; j < h.m; ++j) { const Edge e = eb[j]; if (e.n > best) { best = e.n; child = e.child; } }
+        S st;
+        if constexpr (NLS == NL && WS == W) StateIO<NL>::load_soa(soa, M.G, g, st);
+        else { DState<NLS> t; StateIO<NLS>::load_soa(soa, M.G, g, t); restride<NLS, WS, NL, W>(t, C.n, st); }
+        tafl_play p; p.from_row = p.from_col = p.axis = 0; p.disp = 0;
+        if (best > 0 && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
+            const NodeHdr ch = M.hdr[(size_t)child * M.G + g];
+            Move bm; bm.from = ch.mv_from; bm.dir = ch.mv_dir; bm.dist = ch.mv_dist;
+            bm.to = (uint32_t)((int)bm.from + E::delta(bm.dir) * (int)bm.dist);
+            p = to_play(bm);
+            Moves<NL> nx;
+            E::apply(st, bm, C, nullptr, nx);
+            if constexpr (NLS == NL && WS == W) StateIO<NL>::store_soa(soa, M.G, g, st);
+            else { DState<NLS> t; restride<NL, W, NLS, WS>(st, C.n, t); StateIO<NLS>::store_soa(soa, M.G, g, t); }
+        }
+        sp.plays[(size_t)md * M.G + g] = p;
+        if (md + 1 < sp.n_moves && TAFL_F_STATUS(st.flags) == TAFL_STATUS_ONGOING) {
+            mcts_init_game(M, g, st, C);
+            M.sim_base[g] = (md + 1u) * n_sims; sp.moves_done[g] = md + 1u; sp.start_round[g] = round;
+            return 1;
+        }
+        sp.moves_done[g] = sp.n_moves;                                       // (the plays of the moves it does not make stay all-zero)
+        return 2;
     }
 
     // root statistics (mcts.py:40-41): visited root children in canonical order

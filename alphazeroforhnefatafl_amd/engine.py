@@ -193,6 +193,15 @@ class GameBatch:
         else:
             check(lib().tafl_mcts_run_async_after(self._h, C.byref(p), game_id_base, after._h))
 
+    def selfplay_run(self, n_moves: int, n_sims: int, c_puct: float, seed: int, max_rollout_plies: int, game_id_base: int = 0,
+                     sim_offset: int = 0, flags: int = 0, want_plays: bool = True):
+        """n_moves x (search + most visited play) per game on the device, every game at its own pace (tafl_selfplay_run): per game the same
+        as `for m in range(n_moves): mcts_run(..., sim_offset=sim_offset + m * n_sims); mcts_play_best()`.  Returns the plays [m * n + g]."""
+        p = TaflMctsParams(n_sims, max_rollout_plies, c_puct, seed, sim_offset, flags)
+        plays = (TaflPlay * (self.n * n_moves))() if want_plays else None
+        check(lib().tafl_selfplay_run(self._h, C.byref(p), n_moves, game_id_base, plays))
+        return plays
+
     def mcts_wait(self):
         """Joins the search in flight; runs the rounds its slowest games still need (tafl_mcts_wait)."""
         check(lib().tafl_mcts_wait(self._h))

@@ -361,6 +361,30 @@ def run_variants(args, torch):
         torch.cuda.empty_cache()
         return r
 
+    def selfplay_variant(sims=64, n_moves=8):
+        """tafl_selfplay_run: every game runs n_moves searches of `sims` simulations, each followed by its most visited play, on the device and
+        at its own pace - no barrier between the moves, so the games of the batch are at different phases of their searches and every launch
+        finds the device full (the synchronous headline ends every search in a tail of nearly empty rounds).  Per game identical to the loop
+        { tafl_mcts_run; tafl_mcts_play_best } (GPU test).  Positions: the games' own self-play from the start position, moves 0 .. n_moves-1."""
+        logic = BatchedGameLogic(abi.rules.COPENHAGEN, 11, 128, device=0)
+        batch = logic.new_batch(GAMES_PER_GPU, abi.boards.COPENHAGEN)
+        batch.mcts_reserve(sims)
+        batch.selfplay_run(2, sims, args.cpuct, args.seed, args.max_plies, want_plays=False)        # warm-up
+        batch.reset_fen(abi.boards.COPENHAGEN, abi.rules.COPENHAGEN.starting_side)
+        sync()
+        t0 = time.perf_counter()
+        batch.selfplay_run(n_moves, sims, args.cpuct, args.seed, args.max_plies, want_plays=False)
+        sync()
+        el = time.perf_counter() - t0
+        st = batch.mcts_stats()
+        assert st.faults == 0 and st.sims == GAMES_PER_GPU * sims * n_moves, (st.sims, st.faults)
+        r = {"workload": f"{GAMES_PER_GPU} x 11x11 self-play on the device: {n_moves} moves per game, S={sims} per move, cap {args.max_plies}, every game at its own pace (tafl_selfplay_run)",
+             "value": st.sims / el, "unit": "sims/s", "ms_per_move": el / n_moves * 1e3, "env_steps_per_sec": float(st.rollout_plies) / el,
+             "spec_hit_rate": st.spec_hits / max(st.spec_issued, 1), "plies_per_rollout": float(st.rollout_plies) / max(st.rollouts, 1)}
+        batch.close(); logic.close()
+        return r
+
+    out["selfplay_continuous_S64"] = selfplay_variant(64, 8)
     out["mcts_mixed_positions_S64"] = mcts_variant("copenhagen11", 64, 3, 1, mixed=True)
     out["mcts_S256"] = mcts_variant("copenhagen11", 256, 2, 1)
     out["mcts_S1000"] = mcts_variant("copenhagen11", 1000, 1, 1)
@@ -392,7 +416,7 @@ def make_digest(out):
              "hit %.2f" % (out["mcts"]["spec_hits"] / max(out["mcts"]["spec_issued"], 1)),
              "rollout launch %.2fms x%.0f/step union %.1fms overlap %.2f" % (roof["launch_avg_ms"], roof["launches_per_step"], roof["kernel_ms"], roof["overlap_factor"]),
              "tree %.3fms" % out["kernels_ms"]["k_mcts_tree"]["avg"],
-             "mixed-positions S64 " + m("mcts_mixed_positions_S64"), "S256 " + m("mcts_S256"), "S1000 " + m("mcts_S1000"), "13x13 " + m("mcts_13x13_S64"),
+             "self-play run (8 moves/game, no barrier between moves) " + m("selfplay_continuous_S64"), "mixed-positions S64 " + m("mcts_mixed_positions_S64"), "S256 " + m("mcts_S256"), "S1000 " + m("mcts_S1000"), "13x13 " + m("mcts_13x13_S64"),
              "brandubh7 " + m("mcts_brandubh7_S64"),
              "guided(free evaluator) %s" % ("-" if "guided_engine_only_S64" not in v else "%.1fM" % (v["guided_engine_only_S64"]["value"] / 1e6)),
              "streamed us @65536 11x11: counts %s masks %s step %s step_kth %s rollout %s" % tuple(st("streamed_copenhagen11_65536", k) for k in ("movegen_counts", "movegen_masks", "step", "step_kth", "rollout")),

@@ -349,6 +349,13 @@ int tafl_mcts_best_play(tafl_batch* b, tafl_play* out_plays, uint32_t* out_visit
  * on its batch state (do_valid_play); finished games are left alone (effects.code = TAFL_PLAY_GAME_OVER).  out_* may be NULL
  * (then nothing is copied back and the call only enqueues). */
 int tafl_mcts_play_best(tafl_batch* b, tafl_play* out_plays, tafl_effects* out_effects);
+/* Self-play without leaving the device and without a barrier between the moves: for every game, n_moves times, a search of
+ * params->n_sims simulations from its current state followed by its most visited root play (first maximum) on the batch state - per game
+ * exactly `for m in 0..n_moves: tafl_mcts_run(sim_offset + m * n_sims); tafl_mcts_play_best` - but a game starts its next search as soon
+ * as ITS OWN search is done, so the games of the batch are at different phases of their searches and the device stays full (a batch of
+ * synchronous searches ends every search in a tail of nearly empty rounds).  Games that end stop searching; out_plays[m * n + g] (may be
+ * NULL) is the play game g made at move m, all-zero once its game was over.  tafl_mcts_get_stats afterwards covers all searches. */
+int tafl_selfplay_run(tafl_batch* b, const tafl_mcts_params* params, uint32_t n_moves, uint64_t game_id_base, tafl_play* out_plays);
 
 /* ---- training-tensor writers (the step right after the hot path) ------------------------------
  * tafl_encode_boards: board_to_matrix (game/main.rs:55-83) for every game: uint8 [n * side_len * side_len], row-major;

@@ -75,8 +75,11 @@ struct Host {
         for (uint32_t g = 0; g < cnt; ++g) { S s; state_from_abi<NL>(st[g], s); O::random_advance(s, seed, base + g, plies[g], C, g_force_generic); state_to_abi<NL>(s, n, st[g]); }
         return 0;
     }
+    // n_moves != 0: a self-play run as tafl_selfplay_run drives it (k_mcts_tree_selfplay): `st_io` holds the batch, is advanced in place, and
+    // `plays_out` [n_moves * G] receives the plays
     static int mcts(const tafl_rules* r, uint8_t n, const tafl_state* st, uint32_t G, const tafl_mcts_params* p, uint64_t base,
-                    tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats) {
+                    tafl_root_child* out_children, uint32_t max_children, uint32_t* out_n, tafl_mcts_stats* stats,
+                    uint32_t n_moves = 0, tafl_state* st_io = nullptr, tafl_play* plays_out = nullptr) {
         K C; if (consts(r, n, C)) return -1;
         using IO = StateIO<NL>;
         // same host loop as tafl_mcts_run's two-kernel pipeline: g_spec_k slots exist per game, the search is planned for
@@ -95,12 +98,31 @@ struct Host {
         M.leaf = leaf.data(); M.kind = kind.data(); M.fault = fault.data();
         M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data(); M.spec_meta = smeta.data();
         M.spec_plies = splies.data(); M.spec_node = snode.data(); M.spec_ord = sord.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_w = sw.data();
+        std::vector<uint32_t> simbase(G); M.sim_base = simbase.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; load(st[g], s); O::mcts_init_game(M, g, s, C); }
+        // self-play: the batch as the device holds it (quad-plane SoA in the reference layout), per-game counters, the plays
+        constexpr int NLB = DENSE13 ? 8 : NL, WB = DENSE13 ? 15 : W;
+        std::vector<Quad> soa((size_t)StateIO<NLB>::QUADS * G);
+        std::vector<uint32_t> mdone(G, 0), sround(G, 0);
+        SelfPlay sp; sp.moves_done = mdone.data(); sp.start_round = sround.data(); sp.plays = plays_out; sp.n_moves = n_moves;
+        if (n_moves) {
+            for (uint32_t g = 0; g < G; ++g) { DState<NLB> t; state_from_abi<NLB>(st[g], t); StateIO<NLB>::store_soa(soa.data(), G, g, t); }
+            memset(plays_out, 0, sizeof(tafl_play) * (size_t)n_moves * G);
+        }
         g_round_work.clear();
+        uint32_t round_no = 0, sp_done = 0;
+        const uint32_t planned_sp = g_spec_target ? (p->n_sims + g_spec_target - 1) / g_spec_target : 0;
         auto tree = [&](uint32_t rounds_left) {
             for (uint32_t g = 0; g < G; ++g) {
                 LaneStats ls; memset(&ls, 0, sizeof ls);
+                if (n_moves) {                              // as k_mcts_tree_selfplay: advance, then the plan of the game's own search
+                    const int rr = O::template selfplay_advance<NLB, WB>(M, g, soa.data(), sp, p->n_sims, round_no, C);
+                    if (rr == 2) ++sp_done;
+                    const uint32_t rel = round_no - sround[g];
+                    rounds_left = g_spec_target ? (rel < planned_sp ? planned_sp - rel : 1u) : 0u;
+                    if (!(simn[g] < p->n_sims || kind[g] == 1)) continue;
+                }
                 O::mcts_tree_step(M, g, p->c_puct, p->n_sims, rounds_left, g_spec_target, g_spec_k, C, ls, lm);
                 stats->sims += ls.sims; stats->tree_depth_sum += ls.depth; stats->children_scanned += ls.scanned;
                 stats->terminal_hits += ls.terminal_hits; stats->faults += ls.faults;
@@ -110,7 +132,8 @@ struct Host {
             }
         };
         const uint32_t planned = g_spec_target ? (p->n_sims + g_spec_target - 1) / g_spec_target : 0;
-        for (uint32_t i = 0; i < (p->n_sims + 2) * (g_capacity ? 1 + G / g_capacity : 1); ++i) {
+        for (uint32_t i = 0; i < (p->n_sims + 2) * (g_capacity ? 1 + G / g_capacity : 1) * (n_moves ? n_moves : 1u) + (n_moves ? n_moves : 0u); ++i) {
+            round_no = i;
             tree(g_spec_target ? (i < planned ? planned - i : 1u) : 0u);
             // slot-major like the device's per-slot work lists; with a capacity, playouts beyond it wait for the next round
             uint32_t work = 0;
@@ -120,8 +143,13 @@ struct Host {
                     if (g_capacity && work >= g_capacity) continue;
                     ++work; O::mcts_slot_rollout(M, j, g, p->seed, base + g, p->sim_offset, p->max_rollout_plies, C);
                 }
-            if (work == 0) break;
+            if (work == 0 && (!n_moves || sp_done >= G)) break;
             g_round_work.push_back(work);
+        }
+        if (n_moves) {
+            if (sp_done < G) return -3;
+            for (uint32_t g = 0; g < G; ++g) { DState<NLB> t; StateIO<NLB>::load_soa(soa.data(), G, g, t); state_to_abi<NLB>(t, n, st_io[g]); }
+            return 0;
         }
         for (uint32_t g = 0; g < G; ++g) if (simn[g] != p->n_sims) return -3;
         // the speculation pass must leave no trace: no edge may point at a slot-only child
@@ -217,6 +245,9 @@ void hs_gmcts_leaves(void* h, uint8_t* boards, uint8_t* sides, uint8_t* waiting)
 void hs_gmcts_root_children(void* h, tafl_root_child* out, uint32_t max_children, uint32_t* out_n) { ((GSessionBase*)h)->root_children(out, max_children, out_n); }
 void hs_gmcts_counts(void* h, uint64_t* out4) { GSessionBase* s = (GSessionBase*)h; out4[0] = s->sims; out4[1] = s->predicts; out4[2] = s->terminal_hits; out4[3] = s->faults; }
 void hs_force_generic(int on) { g_force_generic = on != 0; }
+int hs_selfplay(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* st, uint32_t cnt, const tafl_mcts_params* p, uint64_t base, uint32_t n_moves, tafl_play* plays, tafl_mcts_stats* stats) {
+    DISPATCH_DENSE(mcts(r, n, st, cnt, p, base, nullptr, 0, nullptr, stats, n_moves, st, plays))
+}
 void hs_set_spec_k(uint32_t k) { g_spec_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
 void hs_set_spec_target(uint32_t t) { g_spec_target = t > 8 ? 8 : t; }
 void hs_set_capacity(uint32_t c) { g_capacity = c; }

@@ -55,6 +55,9 @@ def lib():
         L.hs_set_capacity.argtypes = [C.c_uint32]
         L.hs_round_work.restype = C.c_uint32
         L.hs_round_work.argtypes = [C.POINTER(C.c_uint32), C.c_uint32]
+        L.hs_selfplay.restype = C.c_int
+        L.hs_selfplay.argtypes = [C.POINTER(TaflRules), C.c_uint8, C.c_uint32, C.POINTER(TaflState), C.c_uint32,
+                                  C.POINTER(TaflMctsParams), C.c_uint64, C.c_uint32, C.POINTER(TaflPlay), C.POINTER(TaflMctsStats)]
         L.hs_set_spec_k.restype = None
         L.hs_set_spec_k.argtypes = [C.c_uint32]
         L.hs_force_generic.restype = None
@@ -107,6 +110,13 @@ class HostSim:
 
     def random_advance(self, states, n, seed, plies, base=0):
         assert lib().hs_random_advance(*self._h(), states, n, seed, plies, base) == 0
+
+    def selfplay(self, states, n, params, n_moves, base=0):
+        """tafl_selfplay_run on the host: `states` is advanced in place; returns (plays [n_moves * n], stats over all searches)."""
+        plays = (TaflPlay * (n * n_moves))()
+        stats = TaflMctsStats()
+        assert lib().hs_selfplay(*self._h(), states, n, C.byref(params), base, n_moves, plays, C.byref(stats)) == 0
+        return plays, stats
 
     def mcts(self, states, n, params, base=0, max_children=256):
         kids = (TaflRootChild * (n * max_children))()

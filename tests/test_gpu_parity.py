@@ -527,6 +527,47 @@ def test_async_searches_equal_the_synchronous_one_and_the_oracle():
     assert pu.states_equal(states, whole.download(), 64), "searches must not modify the batch"
 
 
+@pytest.mark.parametrize("name,G,sims,n_moves,cap", [("copenhagen11", 4096, 32, 5, 160), ("brandubh7", 2048, 40, 12, 64), ("copenhagen13", 512, 16, 3, 96)])
+def test_selfplay_run_equals_the_synchronous_loop(name, G, sims, n_moves, cap):
+    """tafl_selfplay_run (every game searches and plays at its own pace, k_mcts_tree_selfplay) == the loop
+    { tafl_mcts_run(sim_offset = move * n_sims); tafl_mcts_play_best } on the same batch: plays of every move and final states, including
+    games that end on the way (Brandubh: many do) and the 13x13 preset (search in the dense layout, plays applied to the 15-column batch)."""
+    rules, fen, wb, n, lg = _mk(name)
+    glg = gpu_logic(rules, n, wb)
+    a = glg.new_batch(G, fen)
+    plies = (C.c_uint32 * G)(*[(i * 5) % 30 for i in range(G)])
+    a.random_advance(2, plies, 900)
+    states = a.download()
+    b = gpu_batch(rules, n, wb, states, G)
+    want = []
+    for m in range(n_moves):
+        a.mcts_run(sims, 1.0, 6, cap, game_id_base=900, sim_offset=m * sims)
+        plays, _ = a.mcts_play_best()
+        want.append([pu.play_tuple4(plays[g]) for g in range(G)])
+    got = b.selfplay_run(n_moves, sims, 1.0, 6, cap, game_id_base=900)
+    for m in range(n_moves):
+        assert [pu.play_tuple4(got[m * G + g]) for g in range(G)] == want[m], (name, m)
+    fa, fb = a.download(), b.download()
+    assert pu.states_equal(fa, fb, G), pu.first_state_diff(fa, fb, G)
+    st = b.mcts_stats()
+    assert st.faults == 0
+    if name == "brandubh7":
+        assert sum(1 for g in range(G) if fb[g].status != 0) > G // 20          # games did end on the way
+    # oracle spot check of one game: the same loop on the CPU
+    g = 7
+    one = (TaflState * 1)(states[g])
+    for m in range(n_moves):
+        p = TaflMctsParams(sims, cap, 1.0, 6, m * sims, 0)
+        kids, cnt, _ = orc.batch_mcts(lg, one, 1, wb, p, 900 + g)
+        vs = [kids[j].visits for j in range(cnt[0])]
+        sub = (TaflPlay * 1)()
+        if vs and max(vs) > 0 and one[0].status == 0:
+            C.memmove(C.byref(sub[0]), C.byref(kids[vs.index(max(vs))].play), C.sizeof(TaflPlay))
+        assert pu.play_tuple4(sub[0]) == want[m][g], (name, m)
+        orc.batch_step(lg, one, 1, wb, sub)
+    assert bytes(one[0]) == bytes(fb[g])
+
+
 def test_full_size_13x13_properties_65536():
     """BASELINE configs[4] at full size: 65 536 concurrent 13x13 games in the dense 13-column search layout - conservation properties,
     shard invariance and oracle spot ids, as for the 11x11 headline."""

@@ -310,3 +310,53 @@ def test_mcts_undo_log_overflow_only_ends_the_prediction_pass(log_cap):
     finally:
         hostsim.set_spec_k(4, 0, 0)
         hostsim.set_log_cap(16)
+
+
+def _oracle_selfplay(lg, states, G, wb, sims, cap, cpuct, seed, base, n_moves):
+    """The loop tafl_selfplay_run replaces, on the oracle: per move a search with sim_offset = move * sims, then the most visited root
+    play (first maximum, src/mcts.rs:216-227) on every game that has one."""
+    plays_all = []
+    for m in range(n_moves):
+        p = TaflMctsParams(sims, cap, cpuct, seed, m * sims, 0)
+        kids, cnt, _ = orc.batch_mcts(lg, states, G, wb, p, base)
+        sub = (abi.TaflPlay * G)()
+        row = []
+        for g in range(G):
+            vs = [kids[g * 256 + j].visits for j in range(cnt[g])]
+            if vs and max(vs) > 0 and states[g].status == 0:
+                best = kids[g * 256 + vs.index(max(vs))].play
+                C.memmove(C.byref(sub[g]), C.byref(best), C.sizeof(abi.TaflPlay))
+                row.append(pu.play_tuple4(best))
+            else:
+                row.append((0, 0, 0, 0))
+        orc.batch_step(lg, states, G, wb, sub)           # (an all-zero play on a finished game is rejected and changes nothing)
+        plays_all.append(row)
+    return plays_all
+
+
+@pytest.mark.parametrize("name,G,sims,n_moves,k,target,cap", [("brandubh7", 24, 40, 9, 8, 4, 0), ("copenhagen11", 8, 24, 4, 8, 4, 20), ("tablut9", 10, 30, 5, 4, 2, 0),
+                                                             ("copenhagen13", 4, 16, 3, 8, 4, 0)])
+def test_selfplay_run_equals_the_loop_of_searches_and_plays(name, G, sims, n_moves, k, target, cap):
+    """tafl_selfplay_run's per-game state machine (Ops::selfplay_advance: most visited play on the batch state, next search at once, RNG key
+    of move m offset by m * n_sims, plan counted from the launch the game's own search began) == the synchronous loop on the oracle: plays
+    and final states, for games that end on the way too (Brandubh playouts are short and decisive: several of the 24 games finish)."""
+    from tests.hostsim import hostsim
+    rules, fen, wb, n, lg, hs = _mk(name)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 7) % 36 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 3, plies, 50)
+    want_states = pu.clone_states(states, G)
+    want = _oracle_selfplay(lg, want_states, G, wb, sims, 60, 1.0, 8, 50, n_moves)
+    hostsim.set_spec_k(k, target, cap)
+    if name == "copenhagen13":
+        hostsim.set_dense13(True)
+    try:
+        got_states = pu.clone_states(states, G)
+        plays, stats = hs.selfplay(got_states, G, TaflMctsParams(sims, 60, 1.0, 8, 0, 0), n_moves, 50)
+    finally:
+        hostsim.set_spec_k(4, 0, 0)
+        hostsim.set_dense13(False)
+    for m in range(n_moves):
+        assert [pu.play_tuple4(plays[m * G + g]) for g in range(G)] == want[m], (name, m)
+    assert pu.states_equal(want_states, got_states, G), pu.first_state_diff(want_states, got_states, G)
+    assert stats.faults == 0
