@@ -698,6 +698,36 @@ struct Engine {
     static TAFL_HD uint32_t sim_key(uint64_t gk, uint32_t sim) {
         return fmix32((uint32_t)gk ^ (sim * 0x9E3779B1u + 0x7F4A7C15u)) ^ fmix32((uint32_t)(gk >> 32) + sim * 0x85EBCA77u + 0x165667B1u);
     }
+    // Leaf key of the search's playouts (include/taflhip.h "leaf key"): MurmurHash3_x86_32 over the position as layout-independent words -
+    // per row (attacker bits) | (defender bits) << 16, the repetition records, turn, repetition counts, side / mid-pair flags / king tile.
+    // The same value in every board layout (reference stride or dense 13 columns).      oracle: orc_state_hash
+    static TAFL_HD uint32_t mm3_word(uint32_t h, uint32_t k) {
+        k *= 0xCC9E2D51u; k = (k << 15) | (k >> 17); k *= 0x1B873593u;
+        h ^= k; h = (h << 13) | (h >> 19); return h * 5u + 0xE6546B64u;
+    }
+    template <int R>
+    static TAFL_HD uint32_t row_of(const Bits<NL>& a) {
+        constexpr int p = R * W;
+        uint32_t v = a.w[p >> 5] >> (p & 31);
+        if constexpr ((p & 31) + W > 32 && (p >> 5) + 1 < NL) v |= a.w[(p >> 5) + 1] << (32 - (p & 31));
+        return v & ((1u << W) - 1u);
+    }
+    template <int R>
+    static TAFL_HD uint32_t hash_rows(const S& st, uint32_t n, uint32_t h) {
+        if constexpr (R < W) {
+            if ((uint32_t)R < n) h = mm3_word(h, (row_of<R>(st.att) & ((1u << n) - 1u)) | ((row_of<R>(st.def) & ((1u << n) - 1u)) << 16));
+            return hash_rows<R + 1>(st, n, h);
+        } else return h;
+    }
+    static TAFL_HD uint32_t state_hash(const S& st, const K& C) {
+        uint32_t h = hash_rows<0>(st, C.n, C.n);
+        TAFL_UNROLL for (int i = 0; i < 4; ++i) h = mm3_word(h, st.rep[i]);
+        h = mm3_word(h, st.turn);
+        h = mm3_word(h, st.reps);
+        h = mm3_word(h, st.flags & 0x00FF0007u);
+        h ^= (C.n + 7u) * 4u;
+        return fmix32(h);
+    }
     static TAFL_HD uint32_t ply_rand(uint32_t sk, uint32_t ply) { return fmix32(sk + ply * 0x85EBCA77u); }
     static TAFL_HD uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
 

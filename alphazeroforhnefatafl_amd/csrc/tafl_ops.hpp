@@ -863,7 +863,7 @@ struct Ops {
         if (j >= M.spec_n[g] || M.spec_kind[o] != 1) return;
         S st; IO::load_rec(M.spec_state + o * IO::QUADS, st);
         tafl_rollout_result r;
-        playout(st, E::sim_key(E::game_key(seed, game_id), sim_offset + M.sim_base[g] + M.spec_first[g] + j), max_plies, C, r);
+        playout(st, E::sim_key(E::game_key(seed, game_id), sim_offset + M.sim_base[g] + E::state_hash(st, C)), max_plies, C, r);
         M.spec_value[o] = r.value; M.spec_reason[o] = r.reason; M.spec_plies[o] = r.plies; M.spec_kind[o] = 2;
     }
 

@@ -194,7 +194,12 @@ typedef struct tafl_mcts_params {
     uint32_t max_rollout_plies;
     double   c_puct;           /* args.cpuct         src/mcts.py:112 */
     uint64_t seed;
-    uint32_t sim_offset;       /* first simulation index used in the RNG key (normally 0) */
+    uint32_t sim_offset;       /* salt of the playouts' RNG key (normally 0): predict(s) of the random-rollout search is ONE playout from s with
+                                  simulation word sim_offset + leaf key(s) - "leaf key" = MurmurHash3_x86_32, seeded with the side length, over
+                                  the words { per row r: attacker bits | defender bits << 16 (king included) }, rep_ring[0..3], turn,
+                                  attacker_reps | defender_reps << 16, side | attacker_mid_pair << 1 | defender_mid_pair << 2 | king row << 16 |
+                                  king col << 20 - so the value of a leaf is a function of (seed, global game id, sim_offset, position) alone,
+                                  as nnet.predict(canonicalBoard) of src/mcts.py:85 is a function of the board alone */
     uint32_t flags;            /* TAFL_MCTS_FLAG_* | tuning fields; 0 = src/mcts.py semantics, default pipeline */
 } tafl_mcts_params;
 /* semantics bits of tafl_mcts_params.flags.

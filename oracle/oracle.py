@@ -87,6 +87,7 @@ def lib():
         sig("orc_rng", u32, u64, u64, u32, u32)
         sig("orc_rollout_order_plays", i32, vp, vp, P(TaflPlay), i32)
         sig("orc_rollout", i32, vp, vp, u64, u64, u32, u32, P(TaflRolloutResult))
+        sig("orc_state_hash", u32, vp)
         sig("orc_random_advance", i32, vp, vp, u64, u64, u32)
         L._predict_t = C.CFUNCTYPE(None, vp, vp, P(C.c_float), P(C.c_float))
         sig("orc_gmcts_new", vp, vp, vp, C.c_double, L._predict_t, vp)
@@ -223,6 +224,11 @@ class GameLogic:
         r = TaflRolloutResult()
         lib().orc_rollout(self.ptr, state.ptr, seed, game_id, sim, max_plies, C.byref(r))
         return r
+
+    @staticmethod
+    def state_hash(state: "GameState") -> int:
+        """Leaf key of the search's playouts: predict(s) is the playout with simulation word sim_offset + state_hash(s)."""
+        return int(lib().orc_state_hash(state.ptr))
 
     def random_advance(self, state: "GameState", seed: int, game_id: int, plies: int) -> "GameState":
         new = state.clone()

@@ -130,6 +130,8 @@ tafl_play orc_action_decode(uint8_t side_len, uint32_t a);
 /* --- build-defined rollout policy ------------------------------------------------------------ */
 uint32_t orc_rng(uint64_t seed, uint64_t game_id, uint32_t sim, uint32_t ply);
 int orc_rollout_order_plays(const ologic* lg, const ostate* st, tafl_play* out, int cap);
+/* leaf key of the search's playouts: predict(s) = the playout with simulation word sim_offset + orc_state_hash(s) (tafl_oracle.c) */
+uint32_t orc_state_hash(const ostate* st);
 int orc_rollout(const ologic* lg, const ostate* st, uint64_t seed, uint64_t game_id, uint32_t sim,
                 uint32_t max_plies, tafl_rollout_result* out);
 int orc_random_advance(const ologic* lg, ostate* st, uint64_t seed, uint64_t game_id, uint32_t plies);

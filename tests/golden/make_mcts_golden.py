@@ -83,7 +83,7 @@ class RolloutNet:
         self.game, self.seed, self.game_id, self.max_plies = game, seed, game_id, max_plies
 
     def predict(self, b):
-        sim = self.game.root_calls - 1          # index of the running simulation
+        sim = self.game.logic.state_hash(b.state)          # the playout is a function of (seed, game, board): as a network's predict is
         r = self.game.logic.rollout(b.state, self.seed, self.game_id, sim, self.max_plies)
         return np.ones(self.game.getActionSize(), dtype=np.float64), float(r.value)
 
