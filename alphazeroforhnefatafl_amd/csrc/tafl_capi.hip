@@ -326,25 +326,34 @@ __device__ __forceinline__ void mcts_tree_launch(const Consts<NL>& Carg, const M
         const unsigned long long fin = __ballot(live && M.sim_next[g] >= n_sims && M.kind[g] != 1);
         if ((threadIdx.x & 63u) == 0 && fin) atomicAdd(&stats[ST_DONE], (unsigned long long)__popcll(fin));
     }
-    // dense work lists of the playouts this round has to run, one list per priority class = slot index (work[j * stride ..], work_count[j];
+    // dense work lists of the playouts this round has to run, one list per priority class (MctsMem::spec_cls; work[c * stride ..], work_count[c];
     // entry = slot << 27 | game): the playout kernel walks them in class order up to what the device holds at once, so that the most
     // speculative playouts are the ones left for the next round when more is asked for.  One atomic per wave and slot; the loads of all
     // slots, then the atomics of all slots are in flight together (a dependent chain of eight was 8 round trips to L2).
     const uint32_t stride = g_end - g_begin;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t sn = live ? (uint32_t)M.spec_n[g] : 0u;
-    uint8_t kd[TAFL_MCTS_MAX_SLOTS];
-    TAFL_UNROLL for (uint32_t j = 0; j < TAFL_MCTS_MAX_SLOTS; ++j) kd[j] = (live && j < M.spec_k) ? M.spec_kind[(size_t)j * M.G + g] : (uint8_t)0;
+    uint8_t kd[TAFL_MCTS_MAX_SLOTS], cl[TAFL_MCTS_MAX_SLOTS];
+    TAFL_UNROLL for (uint32_t j = 0; j < TAFL_MCTS_MAX_SLOTS; ++j) {
+        const size_t o = (size_t)(j < M.spec_k ? j : 0u) * M.G + g;
+        kd[j] = (live && j < M.spec_k) ? M.spec_kind[o] : (uint8_t)0;
+        cl[j] = (live && j < M.spec_k) ? M.spec_cls[o] : (uint8_t)0;
+    }
+    // the slot of this game whose requested playout has priority class c (a game's requested playouts have distinct classes)
+    uint32_t sl[TAFL_MCTS_MAX_SLOTS];
+    TAFL_UNROLL for (uint32_t c = 0; c < TAFL_MCTS_MAX_SLOTS; ++c) {
+        sl[c] = 0xFFu;
+        TAFL_UNROLL for (uint32_t j = 0; j < TAFL_MCTS_MAX_SLOTS; ++j) sl[c] = (kd[j] == 1 && cl[j] == c) ? j : sl[c];
+    }
     unsigned long long bal[TAFL_MCTS_MAX_SLOTS]; uint32_t base[TAFL_MCTS_MAX_SLOTS];
     TAFL_UNROLL for (uint32_t j = 0; j < TAFL_MCTS_MAX_SLOTS; ++j) {
-        bal[j] = __ballot(j < sn && kd[j] == 1);
+        bal[j] = __ballot(sl[j] != 0xFFu);
         base[j] = 0;
         if (bal[j] != 0ull && (int)lane == __ffsll((long long)bal[j]) - 1) base[j] = atomicAdd(&work_count[j], (uint32_t)__popcll(bal[j]));
     }
     TAFL_UNROLL for (uint32_t j = 0; j < TAFL_MCTS_MAX_SLOTS; ++j) {
         if (bal[j] == 0ull) continue;
         const uint32_t b0 = (uint32_t)__shfl((int)base[j], __ffsll((long long)bal[j]) - 1);
-        if ((bal[j] >> lane) & 1ull) work[(size_t)j * stride + b0 + (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1ull))] = (j << 27) | g;
+        if ((bal[j] >> lane) & 1ull) work[(size_t)j * stride + b0 + (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1ull))] = (sl[j] << 27) | g;
     }
     stat_add(stats, ST_SIMS, ls.sims); stat_add(stats, ST_DEPTH, ls.depth); stat_add(stats, ST_SCANNED, ls.scanned);
     stat_add(stats, ST_TERMINAL, ls.terminal_hits); stat_add(stats, ST_FAULTS, ls.faults);
@@ -438,7 +447,7 @@ __global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_m
             ls.reason_hist4 = 0;
         }
         __threadfence();                                          // slot records written by the tree lanes are read by all lanes
-        const bool work = rg < M.G && rj < M.spec_n[rg] && M.spec_kind[(size_t)rj * M.G + rg] == 1;
+        const bool work = rg < M.G && rj < M.spec_k && M.spec_kind[(size_t)rj * M.G + rg] == 1;
         const unsigned long long wb = __ballot(work);
         if (wb == 0ull) continue;
         if (work) Ops<NL, W>::mcts_slot_rollout(M, rj, rg, seed, base + rg, sim_offset, max_plies, C);
@@ -668,7 +677,7 @@ struct tafl_batch {
     DevBuf best_plays, best_visits, enc, policy;
     DevBuf work, work_count, trace, sim_base, sp_moves_done, sp_start_round, sp_plays;
     uint32_t trace_rounds;           // rounds of the last two-kernel search recorded in `trace` (requested / run playouts per round)
-    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_node, spec_ord, spec_first, spec_n, spec_w;
+    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_ref, spec_cls, spec_pend;
     uint32_t spec_k;                 // playout slots per game that exist (TAFL_MCTS_MAX_SLOTS)
     tafl_mcts_stats last_stats; bool ran;
     bool stats_ok;                   // the counters of the last finished search / self-play run can be read (a self-play run leaves no tree: ran = false)
@@ -881,7 +890,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_meta, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_node, &b->spec_ord, &b->spec_first, &b->spec_n, &b->spec_w, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl, &b->sim_base, &b->sp_moves_done, &b->sp_start_round, &b->sp_plays,
+                      &b->spec_plies, &b->spec_ref, &b->spec_cls, &b->spec_pend, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl, &b->sim_base, &b->sp_moves_done, &b->sp_start_round, &b->sp_plays,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
                       &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
     for (DevBuf* d : bufs) d->release();
@@ -1089,16 +1098,16 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->stats, sizeof(unsigned long long) * ST_COUNT);
     const size_t k = b->spec_k;
     NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * arena_quads(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
-    NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_node, k * n * 4); NEED(b->spec_ord, k * n * 4); NEED(b->spec_first, n * 4);
-    NEED(b->spec_n, n); NEED(b->spec_w, n); NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
+    NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_ref, k * n * 4); NEED(b->spec_cls, k * n); NEED(b->spec_pend, n * 4);
+    NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
     NEED(b->ctrl, sizeof(unsigned long long) * CT_COUNT); NEED(b->sim_base, n * 4);
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
     b->mem.node_top = (uint32_t*)b->node_top.p; b->mem.edge_top = (uint32_t*)b->edge_top.p; b->mem.leaf = (uint32_t*)b->leaf.p;
     b->mem.kind = (uint8_t*)b->kind.p; b->mem.fault = (uint8_t*)b->fault.p;
     b->mem.sim_base = (uint32_t*)b->sim_base.p; b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p; b->mem.spec_meta = (uint32_t*)b->spec_meta.p;
     b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
-    b->mem.spec_node = (uint32_t*)b->spec_node.p; b->mem.spec_ord = (uint32_t*)b->spec_ord.p; b->mem.spec_first = (uint32_t*)b->spec_first.p;
-    b->mem.spec_n = (uint8_t*)b->spec_n.p; b->mem.spec_w = (uint8_t*)b->spec_w.p; b->mem.spec_k = b->spec_k;
+    b->mem.spec_ref = (uint32_t*)b->spec_ref.p; b->mem.spec_cls = (uint8_t*)b->spec_cls.p; b->mem.spec_pend = (uint32_t*)b->spec_pend.p;
+    b->mem.spec_k = b->spec_k;
     b->mem.G = b->n; b->mem.node_cap = (uint32_t)node_cap; b->mem.edge_cap = (uint32_t)edge_cap;
     b->mem.flags = 0;
     b->has_mem = true; b->reserved_sims = max_sims;

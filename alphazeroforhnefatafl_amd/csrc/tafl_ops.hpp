@@ -85,24 +85,26 @@ struct MctsMem {
     uint32_t* leaf;              // [G] leaf of the simulation whose playout value is pending
     uint8_t* kind;               // [G] 0 nothing pending, 1 rollout value pending, 2 terminal value pending
     uint8_t* fault;              // [G]
-    // ---- simulation pipeline (DESIGN.md "speculative playout slots") ------------------------------------------
-    // Slot j of game g is the playout keyed by simulation index spec_first[g] + j.  Slot 0 is the leaf of the pending real
-    // simulation; slots 1.. are PREDICTED expansions: child `spec_ord` of node `spec_node`.
-    uint32_t* sim_base;          // [G] added to the simulation index in the RNG key: 0 for a plain search, move * n_sims in a self-play run
+    // ---- simulation pipeline (DESIGN.md "playout slots") ---------------------------------------------------------------
+    // Every game owns spec_k playout slots.  A slot holds one LEAF the search needs (or is predicted to need) a playout value for: child
+    // number `ord` of node `node` (spec_ref), its prepared state, and - once the playout has run - its value.  The value of a leaf is a
+    // function of the leaf's position alone (Engine::state_hash keys the playout), so a slot stays valid until the search really expands
+    // that child, however many simulations later.  One slot is the leaf of the pending real simulation (spec_pend).
+    uint32_t* sim_base;          // [G] added to the salt of the RNG key: 0 for a plain search, move * n_sims in a self-play run
     uint32_t* sim_next;          // [G] simulations completed so far
     Quad* spec_state;            // [(j * G + g) * QUADS] leaf state of slot j
-    int8_t* spec_value;          // [j * G + g] playout value of slot j
-    uint8_t* spec_kind;          // [j * G + g] 0 unused, 1 playout requested, 2 value ready, 3 no playout needed (terminal child)
+    int8_t* spec_value;          // [j * G + g] playout value of slot j (kind 2); the child's terminal code (kind 3)
+    uint8_t* spec_kind;          // [j * G + g] 0 free, 1 playout requested, 2 value ready, 3 no playout needed (terminal child)
     uint8_t* spec_reason;        // [j * G + g] playout termination reason
-    uint32_t* spec_meta;         // [j * G + g] slot j > 0: the play that leads to its leaf and the leaf's legal-play count:
-                                 //     from | dir << 8 | dist << 10 | n_legal << 16 (lets the real expansion of that child reuse the state)
+    uint8_t* spec_cls;           // [j * G + g] kind 1: priority class of the playout in the round's work lists (0 = the pending leaf; distinct per game)
+    uint32_t* spec_meta;         // [j * G + g] the play that leads to the slot's leaf and the leaf's legal-play count:
+                                 //     from | dir << 8 | dist << 10 | n_legal << 16 (the real expansion of that child reuses state and play)
     uint32_t* spec_plies;        // [j * G + g] plies of the playout
-    uint32_t* spec_node;         // [j * G + g] slot j > 0 is child number spec_ord ...
-    uint32_t* spec_ord;          // [j * G + g] ... of this node (the child's index in the node's edge list when it is really expanded)
-    uint32_t* spec_first;        // [G] simulation index of slot 0
-    uint8_t* spec_n;             // [G] slots issued (placeholders of predicted terminal revisits included)
-    uint8_t* spec_w;             // [G] speculative slots this game may issue next (grows by one per fully consumed issue, shrinks to
-                                 //     what was consumed + 1 after a misprediction)
+    uint32_t* spec_ref;          // [j * G + g] node | ord << 20: the slot's leaf is child number ord of node (its index in the node's edge list once it
+                                 //     is really expanded); ord 0xFFF: the leaf is the node itself (a pending leaf that already exists in the tree)
+    uint32_t* spec_pend;         // [G] slot of the pending leaf (valid while kind[g] == 1) | predicted playouts requested by the last step << 8
+                                 //     | width << 16: predicted playouts this game may request next (grows by one when everything requested
+                                 //     last time was consumed, falls back towards what was consumed otherwise)
     uint32_t G, node_cap, edge_cap, spec_k;      // spec_k: slots per game that exist (capacity of the arrays above)
     uint32_t flags;              // TAFL_MCTS_FLAG_* semantics bits of the running search
 };
@@ -127,6 +129,8 @@ struct LaneStats {
 };
 
 constexpr uint32_t kMctsMaxSlots = 8;     // playout slots per game that can exist (MctsMem::spec_k <= this): bound of the unrolled slot loops
+constexpr uint32_t kMctsMaxPass = 12;     // simulations one prediction pass looks ahead at most (the undo log usually ends it earlier)
+constexpr uint32_t kMctsMaxNodes = 1u << 20;   // node ids fit the 20 bits of MctsMem::spec_ref
 #define TAFL_MCTS_EPS 1e-8       /* src/mcts.py:6 */
 #define TAFL_DRAW_VALUE 1e-4     /* getGameEnded draw convention, DESIGN.md */
 
@@ -357,7 +361,7 @@ struct Ops {
         M.hdr[g] = h;
         IO::store_rec(M.node_state + (size_t)g * IO::QUADS, root);
         M.node_top[g] = 1; M.edge_top[g] = 0; M.leaf[g] = 0; M.kind[g] = 0; M.fault[g] = 0;
-        M.sim_next[g] = 0; M.sim_base[g] = 0; M.spec_n[g] = 0; M.spec_first[g] = 0; M.spec_w[g] = (uint8_t)(M.spec_k > 0 ? M.spec_k - 1 : 0);
+        M.sim_next[g] = 0; M.sim_base[g] = 0; M.spec_pend[g] = (M.spec_k > 0 ? M.spec_k - 1 : 0u) << 16;
         for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;
     }
 
@@ -381,7 +385,6 @@ struct Ops {
     static_assert(sizeof(NodeHdr) == 32, "NodeHdr is eight words");
     static_assert(sizeof(Edge) == 16, "Edge is four words");
     struct StepCtx { uint32_t node_top, edge_top; RootCache rc; };
-    struct SlotView { bool valid; uint8_t kind, reason; int8_t value; uint32_t node, ord, meta, plies; };
     struct SimOut {
         uint32_t leaf; uint8_t kind, term;    // kind: 0 fault, 1 playout needed, 2 terminal
         bool fresh;                  // the leaf was created by this simulation: its edge is new (Nsa = 0) and the fields below are valid
@@ -595,15 +598,53 @@ struct Ops {
 
     // ---- simulation pipeline ----------------------------------------------------------------------------------------
     // Simulations of one game are sequential; the pipeline runs the playouts of several FUTURE simulations of a game beside the
-    // pending one.  When simulation s has to wait for its playout (slot 0 = its leaf), mcts_speculate predicts the expansions of
-    // simulations s+1, s+2, ...: it assumes a value for every playout in flight, backs it up IN PLACE (undo log), runs the same
-    // PUCT selection the real simulation will run, notes which child of which node that selection expands (slot j: node, ordinal,
-    // prepared leaf state) and finally restores the tree bit for bit.  The playouts of all slots run in the same round with the
-    // RNG key of their simulation index.  Every simulation later performs its REAL selection on the committed tree and takes a
-    // slot's value only if the slot was issued for exactly (node, ordinal, this simulation index): same leaf state, same RNG key,
-    // hence the value a fresh playout would return.  Predictions therefore change timing only, never results.
+    // pending one.  When a simulation has to wait for its playout, mcts_speculate predicts the expansions of the following
+    // simulations: it assumes a value for every playout in flight (and takes the REAL value of every leaf whose playout has already
+    // run), backs it up IN PLACE (undo log), runs the same PUCT selection the real simulation will run, notes which child of which node
+    // that selection expands (a slot: node, ordinal, prepared leaf state) and finally restores the tree bit for bit.  The playouts of
+    // all requested slots run in the same round.  Every simulation later performs its REAL selection on the committed tree and takes a
+    // slot's value if a slot holds exactly the child it expands (node, ordinal): same leaf state, hence - the playout being keyed by
+    // the leaf's position - the value a fresh playout would return.  A prediction that does not come true at once is not lost: its slot
+    // waits until the search comes by that child.  Predictions therefore change timing only, never results.
     static constexpr uint32_t VIRT_CHILD = 0xFFFFFFFFu;       // child id of an edge that exists only during the speculation pass
-    static constexpr uint32_t ORD_SELF = 0xFFFFFFFFu;         // spec_ord of slot 0: the slot's leaf is spec_node itself
+    static constexpr uint32_t ORD_SELF = 0xFFFu;              // ordinal of a slot whose leaf is the node itself
+    static constexpr uint32_t NO_SLOT = 0xFFu;
+    static TAFL_HD uint32_t slot_ref(uint32_t node, uint32_t ord) { return node | (ord << 20); }
+
+    // the game's slot table in registers (named scalars behind unrolled selects: an array indexed at run time would live in scratch)
+    struct Pool { uint32_t ref[kMctsMaxSlots]; uint8_t kind[kMctsMaxSlots]; };   // kind 0xFF: the slot does not exist (j >= spec_k)
+    static TAFL_HD void pool_load(const MctsMem& M, uint32_t g, Pool& P) {
+        TAFL_UNROLL for (uint32_t j = 0; j < kMctsMaxSlots; ++j) {
+            const size_t o = (size_t)(j < M.spec_k ? j : 0u) * M.G + g;
+            P.ref[j] = M.spec_ref[o]; P.kind[j] = j < M.spec_k ? M.spec_kind[o] : (uint8_t)0xFF;
+        }
+    }
+    static TAFL_HD uint32_t pool_find(const Pool& P, uint32_t ref) {
+        uint32_t f = NO_SLOT;
+        TAFL_UNROLL for (uint32_t j = 0; j < kMctsMaxSlots; ++j) f = (P.kind[j] >= 1 && P.kind[j] <= 3 && P.ref[j] == ref) ? j : f;
+        return f;
+    }
+    static TAFL_HD uint8_t pool_kind(const Pool& P, uint32_t f) {
+        uint8_t k = 0;
+        TAFL_UNROLL for (uint32_t j = 0; j < kMctsMaxSlots; ++j) k = j == f ? P.kind[j] : k;
+        return k;
+    }
+    static TAFL_HD void pool_set(Pool& P, uint32_t f, uint8_t kind, uint32_t ref) {
+        TAFL_UNROLL for (uint32_t j = 0; j < kMctsMaxSlots; ++j) { P.kind[j] = j == f ? kind : P.kind[j]; P.ref[j] = j == f ? ref : P.ref[j]; }
+    }
+    // a slot for a new leaf: a free one; else, outside `keep`, a terminal child (cheap to find again), a requested playout that has not run,
+    // a value that is ready - in this order, the lowest index among equals.  NO_SLOT: none.
+    static TAFL_HD uint32_t pool_alloc(const Pool& P, uint32_t keep) {
+        uint32_t f = NO_SLOT, best = 0;
+        TAFL_UNROLL for (uint32_t jj = 0; jj < kMctsMaxSlots; ++jj) {
+            const uint32_t j = kMctsMaxSlots - 1u - jj;
+            const uint32_t k = P.kind[j];
+            const uint32_t score = k == 0u ? 4u : k == 3u ? 3u : k == 1u ? 2u : k == 2u ? 1u : 0u;
+            const bool ok = score > 0u && !((keep >> j) & 1u) && score >= best;
+            f = ok ? j : f; best = ok ? score : best;
+        }
+        return f;
+    }
 
     struct SpecLog {                                          // undo log of one speculation pass (LogMem: the caller's scratch)
         uint32_t* eb; uint32_t* hb; uint32_t stride, ne, nh, cap; bool ok;
@@ -642,13 +683,14 @@ struct Ops {
             cur = parent; v = -v; new_edge = false;
         }
     }
-    // Predicts the expansions of simulations first+1 .. first+want-1 after the real leaf `L` of simulation `first` became slot 0.
-    // Returns the number of slots (placeholders included).  `assumed`: value assumed for a playout in flight, seen from the leaf's mover.
-    static TAFL_HD uint32_t mcts_speculate(const MctsMem& M, uint32_t g, uint32_t leaf, uint32_t first, uint32_t want, double c_puct,
-                                           uint32_t n_sims, double assumed, const K& C, LaneStats& ls, StepCtx& X, const LogMem& lm) {
+    // Predicts the expansions of the simulations that follow simulation `first`, whose real leaf `leaf` waits for its playout.
+    // want: playouts this game may have requested in this round, the pending one included.  P: the slot table (kept current), keep: slots
+    // the pass has used (bit j), ncls: next free priority class.  Assumed value of a playout in flight: 0.
+    static TAFL_HD void mcts_speculate(const MctsMem& M, uint32_t g, uint32_t leaf, uint32_t first, uint32_t want, double c_puct,
+                                       uint32_t n_sims, const K& C, LaneStats& ls, StepCtx& X, const LogMem& lm, Pool& P, uint32_t& keep, uint32_t& ncls) {
         SpecLog L; L.eb = lm.base + lm.lane; L.hb = lm.base + (size_t)lm.cap * kUndoEWords * lm.stride + lm.lane; L.stride = lm.stride; L.ne = L.nh = 0; L.cap = lm.cap; L.ok = true;
         uint32_t vtop = X.edge_top;                                // edge arrays that grow during the pass take free arena space, not committed
-        uint32_t cnt = 1;
+        uint32_t req = 1;                                          // playouts requested for this round so far (the pending leaf's)
         // the pending leaf as it will be once its playout value arrives: expanded, its path updated with the assumed value
         {
             NodeHdr lh = hdr_get(M, g, leaf, X);
@@ -656,10 +698,10 @@ struct Ops {
             if (L.ok) { lh.expanded = 1; lh.ns = (M.flags & TAFL_MCTS_FLAG_FPU_INF) ? 1u : 0u; hdr_put(M, g, leaf, lh, X); }
             if (leaf != 0 && L.ok) {
                 const uint32_t parent = lh.parent;
-                spec_backup(M, g, L, parent, hdr_get(M, g, parent, X).edge_base + lh.pslot, -assumed, false, X);
+                spec_backup(M, g, L, parent, hdr_get(M, g, parent, X).edge_base + lh.pslot, -0.0, false, X);
             }
         }
-        for (uint32_t t = 1; t < want && first + t < n_sims && L.ok; ++t) {
+        for (uint32_t t = 1; t < kMctsMaxPass && first + t < n_sims && L.ok; ++t) {
             // the selection walks down in a loop of its own: games of a wave stop at different depths, and the expansion below (the
             // expensive part) must run once for all of them, not once per depth
             uint32_t cur = 0; bool stop = false, placed = false, expand = false;
@@ -669,7 +711,7 @@ struct Ops {
                 if (h.term) {                                     // the simulation ends on a terminal node: its value is exact, no playout
                     if (cur == 0) { stop = true; break; }
                     spec_backup(M, g, L, h.parent, hdr_get(M, g, h.parent, X).edge_base + h.pslot, -term_value(h.term), false, X);
-                    M.spec_kind[(size_t)t * M.G + g] = 0; placed = true;
+                    placed = true;
                     break;
                 }
                 if (!h.expanded) { stop = true; break; }
@@ -685,15 +727,26 @@ struct Ops {
             }
             if (expand) {
                 // predicted expansion: child number h.m of node cur
-                S cst; IO::load_rec(M.node_state + ((size_t)cur * M.G + g) * IO::QUADS, cst);
-                Move mv; mv.from = h.cur_from; mv.to = 0; mv.dir = h.cur_dir; mv.dist = h.cur_dist;
-                Moves<NL> nx;
-                bool ok = E::canon_next(cst, cst.flags & TAFL_F_SIDE, C, mv);
-                if (ok) {
-                    E::apply(cst, mv, C, nullptr, nx);
-                    log_hdr(L, cur, h);
-                    ok = L.ok;
+                const uint32_t ref = slot_ref(cur, h.m);
+                uint32_t f = pool_find(P, ref);
+                const bool known = f != NO_SLOT;
+                const uint8_t fk = pool_kind(P, f);
+                bool ok = true;
+                if ((!known || (fk == 1 && !((keep >> f) & 1u))) && req >= want) ok = false;      // this round's share of playouts is used up
+                if (ok && !known) { f = pool_alloc(P, keep); ok = f != NO_SLOT; }
+                const size_t so = (size_t)(ok ? f : 0u) * M.G + g;
+                S cst{}; Move mv; Moves<NL> nx; nx.total = 0; uint8_t tc = 0; double val = -0.0;
+                if (ok && known) {                                // the leaf is in a slot already: its play from there, its value if it has one
+                    const uint32_t meta = M.spec_meta[so]; const int8_t v = M.spec_value[so];
+                    mv.from = meta & 0xFFu; mv.dir = (meta >> 8) & 3u; mv.dist = (meta >> 10) & 0x3Fu; mv.to = 0;
+                    if (fk == 2) val = -(double)v; else if (fk == 3) val = -term_value((uint8_t)v);
+                } else if (ok) {
+                    IO::load_rec(M.node_state + ((size_t)cur * M.G + g) * IO::QUADS, cst);
+                    mv.from = h.cur_from; mv.to = 0; mv.dir = h.cur_dir; mv.dist = h.cur_dist;
+                    ok = E::canon_next(cst, cst.flags & TAFL_F_SIDE, C, mv);
+                    if (ok) { E::apply(cst, mv, C, nullptr, nx); tc = term_code(cst); if (tc) val = -term_value(tc); }
                 }
+                if (ok) { log_hdr(L, cur, h); ok = L.ok; }
                 uint32_t base = h.edge_base, cap = h.cap;
                 if (ok && h.m == cap) {                           // uncommitted growth into free arena space
                     const uint32_t ncap = cap ? cap * 2u : 4u;
@@ -712,19 +765,20 @@ struct Ops {
                     h.cur_from = (uint16_t)mv.from; h.cur_dir = (uint8_t)mv.dir; h.cur_dist = (uint8_t)mv.dist;
                     hdr_put(M, g, cur, h, X);
                     pos_note(X, cur, slot, 0.0);
-                    const uint8_t tc = term_code(cst);
-                    const size_t so = (size_t)t * M.G + g;
-                    IO::store_rec(M.spec_state + so * IO::QUADS, cst);
-                    M.spec_meta[so] = mv.from | (mv.dir << 8) | (mv.dist << 10) | (nx.total << 16);
-                    M.spec_node[so] = cur; M.spec_ord[so] = slot;
-                    M.spec_kind[so] = tc ? 3 : 1;
-                    if (!tc) ls.spec_issued += 1;
+                    if (!known) {
+                        IO::store_rec(M.spec_state + so * IO::QUADS, cst);
+                        M.spec_meta[so] = mv.from | (mv.dir << 8) | (mv.dist << 10) | (nx.total << 16);
+                        M.spec_ref[so] = ref; M.spec_kind[so] = tc ? 3 : 1; M.spec_value[so] = (int8_t)tc;
+                        pool_set(P, f, tc ? 3 : 1, ref);
+                        if (!tc) ls.spec_issued += 1;
+                    }
+                    if ((known ? fk == 1 : !tc) && !((keep >> f) & 1u)) { M.spec_cls[so] = (uint8_t)ncls; ++ncls; ++req; }
+                    keep |= 1u << f;
                     placed = true;
-                    spec_backup(M, g, L, cur, base + slot, tc ? -term_value(tc) : -assumed, true, X);
+                    spec_backup(M, g, L, cur, base + slot, val, true, X);
                 }
             }
             if (stop || !placed) break;
-            cnt = t + 1;
         }
         // restore the tree (reverse order: a record may have been logged more than once)
         for (uint32_t i = L.ne; i > 0; --i) {
@@ -740,106 +794,97 @@ struct Ops {
             M.hdr[(size_t)r[0] * M.G + g] = h;
         }
         // (the step's register copy of the root - X.rc - still shows the pass's last state: the pass is the last thing a step does with it)
-        return cnt;
     }
 
     // One call advances game g by as many simulations as it can without waiting for a playout.
-    // rounds_left: rounds the host still plans for this search (0: issue spec_k slots whenever possible): a game issues
-    // ceil(remaining / rounds_left) slots, so that a game that lost a round to a misprediction catches up instead of trailing.
-    // target: slots per game and round the plan is made for (0: none).  The slot index is the slot's priority class in the round's work
-    // lists: slot 0 (certain) first, the most speculative last.
-    // wcap: most predicted simulations a game may run beside the pending one (the host lowers it while few predictions come true: a
-    // prediction costs a child expansion in the tree phase whether it is consumed or not).
+    // rounds_left: rounds the host still plans for this search (0: no plan): a game requests ceil(remaining / rounds_left) playouts, so
+    // that a game that lost a round catches up instead of trailing.  target: playouts per game and round the plan is made for (0: none).
+    // wcap: most predicted playouts a game may request beside the pending one (lowered while few predictions come true: a prediction
+    // costs a child expansion in the tree phase whether it is consumed or not).
     static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, uint32_t wcap, const K& C, LaneStats& ls, const LogMem& lm) {
         // everything the step needs from the per-game arrays, fetched side by side
         uint32_t sim = M.sim_next[g];
         const uint8_t kind0 = M.kind[g];
         const uint32_t leaf0 = M.leaf[g];
-        const uint32_t had = M.spec_n[g], first = M.spec_first[g];
-        const uint32_t w0 = M.spec_w[g];
+        const uint32_t pw = M.spec_pend[g];
+        const size_t po = (size_t)(pw & 0xFFu) * M.G + g;
         StepCtx X; X.node_top = M.node_top[g]; X.edge_top = M.edge_top[g];
         root_load(M, g, X); X.rc.pos_valid = false; TAFL_UNROLL for (uint32_t i = 0; i < 4; ++i) X.rc.pos[i] = 0;
-        const uint8_t sk0 = M.spec_kind[g], sr0 = M.spec_reason[g]; const int8_t sv0 = M.spec_value[g]; const uint32_t sp0 = M.spec_plies[g];
-        if (kind0 == 1) {                                        // slot 0 of the previous call
+        const uint8_t sk0 = M.spec_kind[po], sr0 = M.spec_reason[po]; const int8_t sv0 = M.spec_value[po]; const uint32_t sp0 = M.spec_plies[po];
+        Pool P; pool_load(M, g, P);                              // the slot table: registers for the whole step, memory kept current
+        if (kind0 == 1) {                                        // the pending leaf of the previous call
             if (sk0 != 2) return;                                // its playout has not run yet (the round was full): the slots stay requested
             ls.rollouts += 1; ls.rollout_plies += sp0; ls.reason_hist4 += 1ull << (4u * (sr0 & 15u));
             SimOut o; o.leaf = leaf0; o.kind = 1; o.term = 0; o.fresh = false; o.parent = 0; o.pslot = 0; o.eidx = 0;
             mcts_backup(M, g, o, (int)sv0, X); ++sim;
+            M.spec_kind[po] = 0; pool_set(P, pw & 0xFFu, 0, 0u);
         }
-        uint32_t hits = 0;
-        bool pending = false; uint32_t pend_leaf = leaf0;
+        bool pending = false; uint32_t pend_leaf = leaf0, pend_slot = NO_SLOT, hits = 0;
         // The games of a wave take different numbers of turns through the inner loop, so it holds only what is cheap (selection, an
-        // expansion whose state a slot has prepared, backup).  An expansion that needs canon_next + apply (no slot, or the prediction
-        // failed) leaves it and is computed behind it, once per wave; the game then waits for that leaf's playout, and only a terminal
+        // expansion whose state a slot has prepared, backup).  An expansion that needs canon_next + apply (no slot holds that child)
+        // leaves it and is computed behind it, once per wave; the game then waits for that leaf's playout, and only a terminal
         // child sends it round again.
         for (;;) {
             bool deferred = false;
-            SimOut o;
+            SimOut o; o.parent = 0; o.pslot = 0;
             for (;;) {
                 if (sim >= n_sims) break;
-                // the slot issued for this simulation index (if any), fetched beside the selection
-                const uint32_t j = sim - first;
-                SlotView sv; sv.valid = had > 0 && sim > first && j < had;
-                const size_t so = (size_t)(sv.valid ? j : 0u) * M.G + g;
-                sv.kind = M.spec_kind[so]; sv.node = M.spec_node[so]; sv.ord = M.spec_ord[so]; sv.meta = M.spec_meta[so];
-                sv.value = M.spec_value[so]; sv.plies = M.spec_plies[so]; sv.reason = M.spec_reason[so];
                 mcts_select(M, g, c_puct, ls, X, o);
+                uint32_t f = NO_SLOT; uint8_t fk = 0, fr = 0; int8_t fv = 0; uint32_t fp = 0;
                 if (o.kind == 4) {
-                    // If the slot of this simulation index was prepared for exactly this child (same node, same ordinal), its state, play
-                    // and legal-play count are already there: no second canon_next / apply.
-                    if (!(sv.valid && sv.kind >= 1 && sv.node == o.parent && sv.ord == o.pslot)) { deferred = true; break; }
+                    // a slot holds exactly this child (same node, same ordinal): state, play and legal-play count are there, no canon_next / apply
+                    f = pool_find(P, slot_ref(o.parent, o.pslot));
+                    if (f == NO_SLOT) { deferred = true; break; }
+                    fk = pool_kind(P, f);
+                    const size_t so = (size_t)f * M.G + g;
+                    const uint32_t meta = M.spec_meta[so]; fv = M.spec_value[so]; fp = M.spec_plies[so]; fr = M.spec_reason[so];
                     S st; IO::load_rec(M.spec_state + so * IO::QUADS, st);
-                    Move mv; mv.from = sv.meta & 0xFFu; mv.dir = (sv.meta >> 8) & 3u; mv.dist = (sv.meta >> 10) & 0x3Fu; mv.to = 0;
-                    mcts_expand(M, g, ls, X, o, st, mv, sv.meta >> 16);
+                    Move mv; mv.from = meta & 0xFFu; mv.dir = (meta >> 8) & 3u; mv.dist = (meta >> 10) & 0x3Fu; mv.to = 0;
+                    mcts_expand(M, g, ls, X, o, st, mv, meta >> 16);
                 }
-                if (o.kind == 0) { ++sim; continue; }                                   // fault (flagged per game): nothing to back up
-                if (o.kind == 2) { mcts_backup(M, g, o, 0, X); ++sim; continue; }       // terminal node: value known at once
-                const uint32_t L = o.leaf;
-                if (L != 0 && sv.valid && sv.kind == 2) {
-                    uint32_t lp = o.parent, lo = o.pslot;
-                    if (!o.fresh) { const NodeHdr lh = M.hdr[(size_t)L * M.G + g]; lp = lh.parent; lo = lh.pslot; }
-                    if (sv.node == lp && sv.ord == lo) {                                // predicted expansion: reuse its playout
-                        ls.rollouts += 1; ls.rollout_plies += sv.plies; ls.reason_hist4 += 1ull << (4u * (sv.reason & 15u));
-                        ls.spec_hits += 1; ++hits;
-                        mcts_backup(M, g, o, (int)sv.value, X); ++sim;
-                        continue;
-                    }
+                const size_t fo = (size_t)(f != NO_SLOT ? f : 0u) * M.G + g;
+                if (o.kind == 0) { if (f != NO_SLOT) { M.spec_kind[fo] = 0; pool_set(P, f, 0, 0u); } ++sim; continue; }                                    // fault (flagged per game): nothing to back up
+                if (o.kind == 2) { if (f != NO_SLOT) { M.spec_kind[fo] = 0; pool_set(P, f, 0, 0u); } mcts_backup(M, g, o, 0, X); ++sim; continue; }       // terminal node: value known at once
+                if (f != NO_SLOT && fk == 2) {                                          // its playout has run: the value a fresh playout would return
+                    ls.rollouts += 1; ls.rollout_plies += fp; ls.reason_hist4 += 1ull << (4u * (fr & 15u));
+                    ls.spec_hits += 1; ++hits;
+                    M.spec_kind[fo] = 0; pool_set(P, f, 0, 0u);
+                    mcts_backup(M, g, o, (int)fv, X); ++sim;
+                    continue;
                 }
-                pending = true; pend_leaf = L;
+                pending = true; pend_leaf = o.leaf; pend_slot = f;                      // (f: requested, not run yet - that slot is now the pending one)
                 break;                                                                  // wait for the playouts
             }
             if (!deferred) break;
             S st; Move mv; Moves<NL> nx;
             if (!mcts_child_state(M, g, o, C, st, mv, nx)) { M.fault[g] = 1; ls.faults += 1; ++sim; continue; }
             mcts_expand(M, g, ls, X, o, st, mv, nx.total);
-            if (o.kind == 1) { pending = true; pend_leaf = o.leaf; break; }
+            if (o.kind == 1) { pending = true; pend_leaf = o.leaf; pend_slot = NO_SLOT; break; }
             if (o.kind == 2) mcts_backup(M, g, o, 0, X);
             ++sim;
         }
-        if (!pending) M.spec_n[g] = 0;
-        // Issue new slots: slot 0 = the waiting leaf, slots 1.. = the predicted expansions of the following simulations.  This sits BEHIND
-        // the loop on purpose: the games of a wave leave the loop after different numbers of consumed slots, and inside the loop the wave
-        // would run the prediction pass (the most expensive code of the step) once per distinct count instead of once.
+        // Request playouts: the waiting leaf's and those of the predicted expansions.  This sits BEHIND the loop on purpose: the games of a
+        // wave leave the loop after different numbers of consumed slots, and inside the loop the wave would run the prediction pass (the
+        // most expensive code of the step) once per distinct count instead of once.
         if (pending) {
             const uint32_t L = pend_leaf;
-            S lst; IO::load_rec(M.node_state + ((size_t)L * M.G + g) * IO::QUADS, lst);
-            IO::store_rec(M.spec_state + (size_t)g * IO::QUADS, lst);
-            M.spec_kind[g] = 1; M.spec_node[g] = L; M.spec_ord[g] = ORD_SELF;
-            // width: what the last issue showed to be predictable (+1), capped by the slots that exist and by the deadline
-            uint32_t w = w0;
-            if (had > 1) {
-                uint32_t issued = 0;
-                uint8_t sk[kMctsMaxSlots];
-                TAFL_UNROLL for (uint32_t t = 1; t < kMctsMaxSlots; ++t) sk[t] = M.spec_kind[(size_t)(t < had ? t : 0u) * M.G + g];      // independent loads
-                TAFL_UNROLL for (uint32_t t = 1; t < kMctsMaxSlots; ++t) issued += (t < had && (sk[t] == 1 || sk[t] == 2)) ? 1u : 0u;
-                // a fully consumed issue widens by one; after a miss the width falls half-way back to what came true (+1)
-                w = (hits >= issued) ? w + 1u : ((w + hits + 1u) / 2u > hits + 1u ? (w + hits + 1u) / 2u : hits + 1u);
+            if (pend_slot == NO_SLOT) {                          // the leaf was not in a slot: it takes one (nothing is kept: there always is one)
+                pend_slot = pool_alloc(P, 0u);
+                const size_t so = (size_t)pend_slot * M.G + g;
+                S lst; IO::load_rec(M.node_state + ((size_t)L * M.G + g) * IO::QUADS, lst);
+                IO::store_rec(M.spec_state + so * IO::QUADS, lst);
+                M.spec_kind[so] = 1; M.spec_ref[so] = slot_ref(L, ORD_SELF);
+                pool_set(P, pend_slot, 1, slot_ref(L, ORD_SELF));
             }
+            M.spec_cls[(size_t)pend_slot * M.G + g] = 0;
+            // width: what the last request showed to be predictable (+1); after a miss half-way back to what came true (+1)
+            const uint32_t issued = (pw >> 8) & 0xFFu;
+            uint32_t w = pw >> 16;
+            if (issued > 0) w = (hits >= issued) ? w + 1u : ((w + hits + 1u) / 2u > hits + 1u ? (w + hits + 1u) / 2u : hits + 1u);
             if (w > M.spec_k - 1) w = M.spec_k - 1;
-            M.spec_w[g] = (uint8_t)w;
+            const uint32_t w_own = w;
             if (w > wcap) w = wcap;
-            // rounds_left == 1: the plan is through and the device is emptying (the host says so): a wasted playout costs nothing, every slot
-            // that exists is used.  rounds_left == 0: no plan, the game keeps to its own hit history.
+            // rounds_left == 1: the plan is through and the device is emptying (the host says so): every slot that exists is used.
             uint32_t want = M.spec_k;
             if (rounds_left > 1) {
                 const uint32_t rem = n_sims - sim;
@@ -847,20 +892,25 @@ struct Ops {
                 if (want > w + 1) want = w + 1;
             } else if (rounds_left == 0 && want > w + 1) want = w + 1;
             if (want > M.spec_k) want = M.spec_k;
-            uint32_t cnt = 1;
-            if (want > 1 && sim + 1 < n_sims && lm.cap > 0) cnt = mcts_speculate(M, g, L, sim, want, c_puct, n_sims, 0.0, C, ls, X, lm);
-            for (uint32_t t = cnt; t < M.spec_k; ++t) M.spec_kind[(size_t)t * M.G + g] = 0;
-            M.spec_n[g] = (uint8_t)cnt; M.spec_first[g] = sim;
+            uint32_t keep = 1u << pend_slot, ncls = 1;
+            const uint32_t issued0 = ls.spec_issued;
+            if (want > 1 && sim + 1 < n_sims && lm.cap > 0) mcts_speculate(M, g, L, sim, want, c_puct, n_sims, C, ls, X, lm, P, keep, ncls);
+            M.spec_pend[g] = pend_slot | ((ls.spec_issued - issued0) << 8) | (w_own << 16);
+            // requested playouts the pass did not come by (left over from a round that was full) run last
+            TAFL_UNROLL for (uint32_t j = 0; j < kMctsMaxSlots; ++j)
+                if (P.kind[j] == 1 && !((keep >> j) & 1u)) { M.spec_cls[(size_t)j * M.G + g] = (uint8_t)ncls; ++ncls; }
+        } else {
+            for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;      // the search is over: what is left in the slots is not needed
         }
         M.sim_next[g] = sim; M.node_top[g] = X.node_top; M.edge_top[g] = X.edge_top;
         M.leaf[g] = pend_leaf; M.kind[g] = pending ? 1 : 0;
     }
 
-    // playout of slot j of game g (predict() of mcts.py:85 in random-rollout mode)
+    // playout of slot j of game g (predict() of mcts.py:85 in random-rollout mode), keyed by the leaf's position
     static TAFL_HD void mcts_slot_rollout(const MctsMem& M, uint32_t j, uint32_t g, uint64_t seed, uint64_t game_id, uint32_t sim_offset,
                                           uint32_t max_plies, const K& C) {
         const size_t o = (size_t)j * M.G + g;
-        if (j >= M.spec_n[g] || M.spec_kind[o] != 1) return;
+        if (j >= M.spec_k || M.spec_kind[o] != 1) return;
         S st; IO::load_rec(M.spec_state + o * IO::QUADS, st);
         tafl_rollout_result r;
         playout(st, E::sim_key(E::game_key(seed, game_id), sim_offset + M.sim_base[g] + E::state_hash(st, C)), max_plies, C, r);

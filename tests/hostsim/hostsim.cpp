@@ -88,8 +88,8 @@ struct Host {
         std::vector<Quad> ns((size_t)M.node_cap * G * IO::QUADS), sst((size_t)M.spec_k * G * IO::QUADS);
         std::vector<NodeHdr> hdr((size_t)M.node_cap * G);
         std::vector<Edge> edges((size_t)M.edge_cap * G);
-        std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), sfirst(G), splies((size_t)M.spec_k * G), smeta((size_t)M.spec_k * G), snode((size_t)M.spec_k * G), sord((size_t)M.spec_k * G);
-        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), sn(G), sw(G);
+        std::vector<uint32_t> ntop(G), etop(G), leaf(G), simn(G), spend(G), splies((size_t)M.spec_k * G), smeta((size_t)M.spec_k * G), sref((size_t)M.spec_k * G);
+        std::vector<uint8_t> kind(G), fault(G), skind((size_t)M.spec_k * G), sreason((size_t)M.spec_k * G), scls((size_t)M.spec_k * G);
         std::vector<int8_t> sval((size_t)M.spec_k * G);
         // the undo log of the prediction pass: one lane's scratch (the device keeps 64 of them side by side in LDS)
         std::vector<uint32_t> logw((size_t)g_log_cap * (kUndoEWords + kUndoHWords) + 1);
@@ -97,7 +97,7 @@ struct Host {
         M.node_state = ns.data(); M.hdr = hdr.data(); M.edges = edges.data(); M.node_top = ntop.data(); M.edge_top = etop.data();
         M.leaf = leaf.data(); M.kind = kind.data(); M.fault = fault.data();
         M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data(); M.spec_meta = smeta.data();
-        M.spec_plies = splies.data(); M.spec_node = snode.data(); M.spec_ord = sord.data(); M.spec_first = sfirst.data(); M.spec_n = sn.data(); M.spec_w = sw.data();
+        M.spec_plies = splies.data(); M.spec_ref = sref.data(); M.spec_cls = scls.data(); M.spec_pend = spend.data();
         std::vector<uint32_t> simbase(G); M.sim_base = simbase.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; load(st[g], s); O::mcts_init_game(M, g, s, C); }
@@ -135,13 +135,17 @@ struct Host {
         for (uint32_t i = 0; i < (p->n_sims + 2) * (g_capacity ? 1 + G / g_capacity : 1) * (n_moves ? n_moves : 1u) + (n_moves ? n_moves : 0u); ++i) {
             round_no = i;
             tree(g_spec_target ? (i < planned ? planned - i : 1u) : 0u);
-            // slot-major like the device's per-slot work lists; with a capacity, playouts beyond it wait for the next round
+            // class-major like the device's per-class work lists; with a capacity, playouts beyond it wait for the next round
             uint32_t work = 0;
-            for (uint32_t j = 0; j < M.spec_k; ++j)
+            for (uint32_t c = 0; c < kMctsMaxSlots; ++c)
                 for (uint32_t g = 0; g < G; ++g) {
-                    if (!(j < sn[g] && skind[(size_t)j * G + g] == 1)) continue;
+                    if (!(simn[g] < p->n_sims || kind[g] == 1)) continue;
+                    uint32_t found = 0, slot = 0;
+                    for (uint32_t j = 0; j < M.spec_k; ++j) if (skind[(size_t)j * G + g] == 1 && scls[(size_t)j * G + g] == c) { ++found; slot = j; }
+                    if (found > 1) return -5;                 // a game's requested playouts must have distinct classes
+                    if (!found) continue;
                     if (g_capacity && work >= g_capacity) continue;
-                    ++work; O::mcts_slot_rollout(M, j, g, p->seed, base + g, p->sim_offset, p->max_rollout_plies, C);
+                    ++work; O::mcts_slot_rollout(M, slot, g, p->seed, base + g, p->sim_offset, p->max_rollout_plies, C);
                 }
             if (work == 0 && (!n_moves || sp_done >= G)) break;
             g_round_work.push_back(work);
