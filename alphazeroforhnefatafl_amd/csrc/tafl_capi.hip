@@ -314,14 +314,14 @@ __device__ __forceinline__ void mcts_tree_launch(const Consts<NL>& Carg, const M
     // until then 0 = every game keeps to what its own hit history allows (a long search whose predictions fail runs far beyond the plan
     // with every game still alive: S = 1000 runs 44 M sims/s this way, 39 M otherwise).  Both only steer WHEN playouts run, never a result.
     uint32_t rounds_left;
-    if constexpr (SP) { const uint32_t rel = live ? round - sp.start_round[g] : 0u; rounds_left = rel < planned ? planned - rel : 1u; }      // per game
+    if constexpr (SP) { const uint32_t rel = live ? round - sp.start_round[g] : 0u; rounds_left = rel < planned ? planned - rel : 0u; }      // per game (the device never empties before the run's end)
     else if (round < planned) rounds_left = planned - round;
     else rounds_left = (probe_every == 0u || 4ull * ld_counter(&stats[ST_DONE]) >= 3ull * (unsigned long long)M.G) ? 1u : 0u;
     const uint32_t wcap = (uint32_t)ld_counter(&ctrl[CT_WCAP]);
     // the undo log of the prediction pass: LDS, one log per lane, word-interleaved (tafl_ops.hpp LogMem)
     extern __shared__ uint32_t tree_lds[];
     LogMem lm; lm.base = tree_lds; lm.stride = TAFL_BLOCK; lm.lane = threadIdx.x & 63u; lm.cap = TAFL_MCTS_UNDO_CAP;
-    if (live) Ops<NL, W>::mcts_tree_step(M, g, c_puct, n_sims, rounds_left, target, wcap, C, ls, lm);
+    if (live) Ops<NL, W>::mcts_tree_step(M, g, c_puct, n_sims, rounds_left, Ops<NL, W>::mcts_scenarios(rounds_left, planned), wcap, C, ls, lm);
     if constexpr (!SP) {   // games that completed their last simulation in this launch (a finished game is never live again: counted once)
         const unsigned long long fin = __ballot(live && M.sim_next[g] >= n_sims && M.kind[g] != 1);
         if ((threadIdx.x & 63u) == 0 && fin) atomicAdd(&stats[ST_DONE], (unsigned long long)__popcll(fin));
@@ -440,7 +440,7 @@ __global__ TAFL_KATTR __launch_bounds__(TAFL_BLOCK, TAFL_ROLLOUT_WAVES) void k_m
     for (uint32_t round = 0; round < max_rounds; ++round) {
         const bool live = lane < GPW && tg < M.G && (M.sim_next[tg] < n_sims || M.kind[tg] == 1);
         if (__ballot(live) == 0ull) break;                        // every game of this wave has finished
-        if (live) Ops<NL, W>::mcts_tree_step(M, tg, c_puct, n_sims, 0u, 0u, K, C, ls, lm);
+        if (live) Ops<NL, W>::mcts_tree_step(M, tg, c_puct, n_sims, 0u, 2u, K, C, ls, lm);
         finished += (uint32_t)__popcll(__ballot(live && M.sim_next[tg] >= n_sims && M.kind[tg] != 1));
         if ((round & 3u) == 3u) {                                 // the packed 4-bit reason counters hold 15: at most 2 playouts are consumed per round
             for (uint32_t r = 0; r < 16; ++r) stat_add(stats, ST_REASON0 + r, (uint32_t)((ls.reason_hist4 >> (4u * r)) & 15ull));
@@ -677,7 +677,7 @@ struct tafl_batch {
     DevBuf best_plays, best_visits, enc, policy;
     DevBuf work, work_count, trace, sim_base, sp_moves_done, sp_start_round, sp_plays;
     uint32_t trace_rounds;           // rounds of the last two-kernel search recorded in `trace` (requested / run playouts per round)
-    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_ref, spec_cls, spec_pend;
+    DevBuf sim_next, spec_state, spec_meta, spec_value, spec_kind, spec_reason, spec_plies, spec_ref, spec_cls, spec_pend, spec_bias;
     uint32_t spec_k;                 // playout slots per game that exist (TAFL_MCTS_MAX_SLOTS)
     tafl_mcts_stats last_stats; bool ran;
     bool stats_ok;                   // the counters of the last finished search / self-play run can be read (a self-play run leaves no tree: ran = false)
@@ -890,7 +890,7 @@ int tafl_batch_destroy(tafl_batch* b) {
     DevBuf* bufs[] = {&b->plays, &b->effects, &b->counts, &b->masks, &b->codes, &b->ranks, &b->results, &b->out_plays, &b->u8out, &b->plies,
                       &b->node_state, &b->hdr, &b->edges, &b->node_top, &b->edge_top, &b->leaf, &b->kind, &b->fault, &b->stats,
                       &b->children, &b->children_n, &b->visits, &b->sim_next, &b->spec_state, &b->spec_meta, &b->spec_value, &b->spec_kind, &b->spec_reason,
-                      &b->spec_plies, &b->spec_ref, &b->spec_cls, &b->spec_pend, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl, &b->sim_base, &b->sp_moves_done, &b->sp_start_round, &b->sp_plays,
+                      &b->spec_plies, &b->spec_ref, &b->spec_cls, &b->spec_pend, &b->spec_bias, &b->best_plays, &b->best_visits, &b->enc, &b->policy, &b->work, &b->work_count, &b->trace, &b->ctrl, &b->sim_base, &b->sp_moves_done, &b->sp_start_round, &b->sp_plays,
                       &b->g_node_state, &b->g_hdr, &b->g_pedge, &b->g_edges, &b->g_node_top, &b->g_edge_top, &b->g_leaf, &b->g_kind, &b->g_fault, &b->g_sims,
                       &b->g_stats, &b->g_priors, &b->g_values, &b->g_boards, &b->g_sides, &b->g_wait};
     for (DevBuf* d : bufs) d->release();
@@ -1098,7 +1098,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     NEED(b->stats, sizeof(unsigned long long) * ST_COUNT);
     const size_t k = b->spec_k;
     NEED(b->sim_next, n * 4); NEED(b->spec_state, k * n * arena_quads(c) * sizeof(Quad)); NEED(b->spec_value, k * n); NEED(b->spec_kind, k * n); NEED(b->spec_meta, k * n * 4);
-    NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_ref, k * n * 4); NEED(b->spec_cls, k * n); NEED(b->spec_pend, n * 4);
+    NEED(b->spec_reason, k * n); NEED(b->spec_plies, k * n * 4); NEED(b->spec_ref, k * n * 4); NEED(b->spec_cls, k * n); NEED(b->spec_pend, n * 4); NEED(b->spec_bias, n * 4);
     NEED(b->work, k * n * 4); NEED(b->work_count, 4 * 2 * TAFL_MCTS_MAX_SLOTS * TAFL_MCTS_MAX_PARTS); NEED(b->trace, 8 * TAFL_MCTS_TRACE_ROUNDS);
     NEED(b->ctrl, sizeof(unsigned long long) * CT_COUNT); NEED(b->sim_base, n * 4);
     b->mem.node_state = (Quad*)b->node_state.p; b->mem.hdr = (NodeHdr*)b->hdr.p; b->mem.edges = (Edge*)b->edges.p;
@@ -1106,7 +1106,7 @@ int tafl_mcts_reserve(tafl_batch* b, uint32_t max_sims) {
     b->mem.kind = (uint8_t*)b->kind.p; b->mem.fault = (uint8_t*)b->fault.p;
     b->mem.sim_base = (uint32_t*)b->sim_base.p; b->mem.sim_next = (uint32_t*)b->sim_next.p; b->mem.spec_state = (Quad*)b->spec_state.p; b->mem.spec_value = (int8_t*)b->spec_value.p; b->mem.spec_meta = (uint32_t*)b->spec_meta.p;
     b->mem.spec_kind = (uint8_t*)b->spec_kind.p; b->mem.spec_reason = (uint8_t*)b->spec_reason.p; b->mem.spec_plies = (uint32_t*)b->spec_plies.p;
-    b->mem.spec_ref = (uint32_t*)b->spec_ref.p; b->mem.spec_cls = (uint8_t*)b->spec_cls.p; b->mem.spec_pend = (uint32_t*)b->spec_pend.p;
+    b->mem.spec_ref = (uint32_t*)b->spec_ref.p; b->mem.spec_cls = (uint8_t*)b->spec_cls.p; b->mem.spec_pend = (uint32_t*)b->spec_pend.p; b->mem.spec_bias = (uint32_t*)b->spec_bias.p;
     b->mem.spec_k = b->spec_k;
     b->mem.G = b->n; b->mem.node_cap = (uint32_t)node_cap; b->mem.edge_cap = (uint32_t)edge_cap;
     b->mem.flags = 0;

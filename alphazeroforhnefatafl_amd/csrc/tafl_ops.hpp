@@ -105,6 +105,8 @@ struct MctsMem {
     uint32_t* spec_pend;         // [G] slot of the pending leaf (valid while kind[g] == 1) | predicted playouts requested by the last step << 8
                                  //     | width << 16: predicted playouts this game may request next (grows by one when everything requested
                                  //     last time was consumed, falls back towards what was consumed otherwise)
+    uint32_t* spec_bias;         // [G] playouts consumed by this search that the defender won | that the attacker won << 16 (steers the prediction
+                                 //     pass only: which value a playout in flight is assumed to return)
     uint32_t G, node_cap, edge_cap, spec_k;      // spec_k: slots per game that exist (capacity of the arrays above)
     uint32_t flags;              // TAFL_MCTS_FLAG_* semantics bits of the running search
 };
@@ -130,6 +132,7 @@ struct LaneStats {
 
 constexpr uint32_t kMctsMaxSlots = 8;     // playout slots per game that can exist (MctsMem::spec_k <= this): bound of the unrolled slot loops
 constexpr uint32_t kMctsMaxPass = 12;     // simulations one prediction pass looks ahead at most (the undo log usually ends it earlier)
+constexpr uint32_t kMctsExtraReq = 2;      // playouts the second scenario of a prediction pass may request beyond the round's share
 constexpr uint32_t kMctsMaxNodes = 1u << 20;   // node ids fit the 20 bits of MctsMem::spec_ref
 #define TAFL_MCTS_EPS 1e-8       /* src/mcts.py:6 */
 #define TAFL_DRAW_VALUE 1e-4     /* getGameEnded draw convention, DESIGN.md */
@@ -361,7 +364,7 @@ struct Ops {
         M.hdr[g] = h;
         IO::store_rec(M.node_state + (size_t)g * IO::QUADS, root);
         M.node_top[g] = 1; M.edge_top[g] = 0; M.leaf[g] = 0; M.kind[g] = 0; M.fault[g] = 0;
-        M.sim_next[g] = 0; M.sim_base[g] = 0; M.spec_pend[g] = (M.spec_k > 0 ? M.spec_k - 1 : 0u) << 16;
+        M.sim_next[g] = 0; M.sim_base[g] = 0; M.spec_pend[g] = (M.spec_k > 0 ? M.spec_k - 1 : 0u) << 16; M.spec_bias[g] = 0;
         for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;
     }
 
@@ -610,6 +613,11 @@ struct Ops {
     static constexpr uint32_t ORD_SELF = 0xFFFu;              // ordinal of a slot whose leaf is the node itself
     static constexpr uint32_t NO_SLOT = 0xFFu;
     static TAFL_HD uint32_t slot_ref(uint32_t node, uint32_t ord) { return node | (ord << 20); }
+    // increment of MctsMem::spec_bias for a playout of value v (seen from the mover of a leaf whose state has these flags)
+    static TAFL_HD uint32_t bias_of(uint32_t leaf_flags, int v) {
+        const bool def_mover = (leaf_flags & TAFL_F_SIDE) != 0u;
+        return v == 0 ? 0u : ((v > 0) == def_mover ? 1u : 0x10000u);
+    }
 
     // the game's slot table in registers (named scalars behind unrolled selects: an array indexed at run time would live in scratch)
     struct Pool { uint32_t ref[kMctsMaxSlots]; uint8_t kind[kMctsMaxSlots]; };   // kind 0xFF: the slot does not exist (j >= spec_k)
@@ -687,10 +695,9 @@ struct Ops {
     // want: playouts this game may have requested in this round, the pending one included.  P: the slot table (kept current), keep: slots
     // the pass has used (bit j), ncls: next free priority class.  Assumed value of a playout in flight: 0.
     static TAFL_HD void mcts_speculate(const MctsMem& M, uint32_t g, uint32_t leaf, uint32_t first, uint32_t want, double c_puct,
-                                       uint32_t n_sims, const K& C, LaneStats& ls, StepCtx& X, const LogMem& lm, Pool& P, uint32_t& keep, uint32_t& ncls) {
+                                       uint32_t n_sims, const K& C, LaneStats& ls, StepCtx& X, const LogMem& lm, Pool& P, uint32_t& keep, uint32_t& ncls, uint32_t& req, double a_pend) {
         SpecLog L; L.eb = lm.base + lm.lane; L.hb = lm.base + (size_t)lm.cap * kUndoEWords * lm.stride + lm.lane; L.stride = lm.stride; L.ne = L.nh = 0; L.cap = lm.cap; L.ok = true;
         uint32_t vtop = X.edge_top;                                // edge arrays that grow during the pass take free arena space, not committed
-        uint32_t req = 1;                                          // playouts requested for this round so far (the pending leaf's)
         // the pending leaf as it will be once its playout value arrives: expanded, its path updated with the assumed value
         {
             NodeHdr lh = hdr_get(M, g, leaf, X);
@@ -698,7 +705,7 @@ struct Ops {
             if (L.ok) { lh.expanded = 1; lh.ns = (M.flags & TAFL_MCTS_FLAG_FPU_INF) ? 1u : 0u; hdr_put(M, g, leaf, lh, X); }
             if (leaf != 0 && L.ok) {
                 const uint32_t parent = lh.parent;
-                spec_backup(M, g, L, parent, hdr_get(M, g, parent, X).edge_base + lh.pslot, -0.0, false, X);
+                spec_backup(M, g, L, parent, hdr_get(M, g, parent, X).edge_base + lh.pslot, -a_pend, false, X);
             }
         }
         for (uint32_t t = 1; t < kMctsMaxPass && first + t < n_sims && L.ok; ++t) {
@@ -798,10 +805,10 @@ struct Ops {
 
     // One call advances game g by as many simulations as it can without waiting for a playout.
     // rounds_left: rounds the host still plans for this search (0: no plan): a game requests ceil(remaining / rounds_left) playouts, so
-    // that a game that lost a round catches up instead of trailing.  target: playouts per game and round the plan is made for (0: none).
+    // that a game that lost a round catches up instead of trailing.  scen: scenario passes of the prediction (1 or 2, mcts_scenarios).
     // wcap: most predicted playouts a game may request beside the pending one (lowered while few predictions come true: a prediction
     // costs a child expansion in the tree phase whether it is consumed or not).
-    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t target, uint32_t wcap, const K& C, LaneStats& ls, const LogMem& lm) {
+    static TAFL_HD void mcts_tree_step(const MctsMem& M, uint32_t g, double c_puct, uint32_t n_sims, uint32_t rounds_left, uint32_t scen, uint32_t wcap, const K& C, LaneStats& ls, const LogMem& lm) {
         // everything the step needs from the per-game arrays, fetched side by side
         uint32_t sim = M.sim_next[g];
         const uint8_t kind0 = M.kind[g];
@@ -811,12 +818,15 @@ struct Ops {
         StepCtx X; X.node_top = M.node_top[g]; X.edge_top = M.edge_top[g];
         root_load(M, g, X); X.rc.pos_valid = false; TAFL_UNROLL for (uint32_t i = 0; i < 4; ++i) X.rc.pos[i] = 0;
         const uint8_t sk0 = M.spec_kind[po], sr0 = M.spec_reason[po]; const int8_t sv0 = M.spec_value[po]; const uint32_t sp0 = M.spec_plies[po];
+        const uint32_t sf0 = M.spec_state[po * IO::QUADS + (IO::QUADS - 1)].w;      // flags word of the pending leaf's state (its mover)
+        uint32_t bias = M.spec_bias[g];
         Pool P; pool_load(M, g, P);                              // the slot table: registers for the whole step, memory kept current
         if (kind0 == 1) {                                        // the pending leaf of the previous call
             if (sk0 != 2) return;                                // its playout has not run yet (the round was full): the slots stay requested
             ls.rollouts += 1; ls.rollout_plies += sp0; ls.reason_hist4 += 1ull << (4u * (sr0 & 15u));
             SimOut o; o.leaf = leaf0; o.kind = 1; o.term = 0; o.fresh = false; o.parent = 0; o.pslot = 0; o.eidx = 0;
             mcts_backup(M, g, o, (int)sv0, X); ++sim;
+            bias += bias_of(sf0, sv0);
             M.spec_kind[po] = 0; pool_set(P, pw & 0xFFu, 0, 0u);
         }
         bool pending = false; uint32_t pend_leaf = leaf0, pend_slot = NO_SLOT, hits = 0;
@@ -830,7 +840,7 @@ struct Ops {
             for (;;) {
                 if (sim >= n_sims) break;
                 mcts_select(M, g, c_puct, ls, X, o);
-                uint32_t f = NO_SLOT; uint8_t fk = 0, fr = 0; int8_t fv = 0; uint32_t fp = 0;
+                uint32_t f = NO_SLOT; uint8_t fk = 0, fr = 0; int8_t fv = 0; uint32_t fp = 0, fflags = 0;
                 if (o.kind == 4) {
                     // a slot holds exactly this child (same node, same ordinal): state, play and legal-play count are there, no canon_next / apply
                     f = pool_find(P, slot_ref(o.parent, o.pslot));
@@ -839,6 +849,7 @@ struct Ops {
                     const size_t so = (size_t)f * M.G + g;
                     const uint32_t meta = M.spec_meta[so]; fv = M.spec_value[so]; fp = M.spec_plies[so]; fr = M.spec_reason[so];
                     S st; IO::load_rec(M.spec_state + so * IO::QUADS, st);
+                    fflags = st.flags;
                     Move mv; mv.from = meta & 0xFFu; mv.dir = (meta >> 8) & 3u; mv.dist = (meta >> 10) & 0x3Fu; mv.to = 0;
                     mcts_expand(M, g, ls, X, o, st, mv, meta >> 16);
                 }
@@ -847,7 +858,7 @@ struct Ops {
                 if (o.kind == 2) { if (f != NO_SLOT) { M.spec_kind[fo] = 0; pool_set(P, f, 0, 0u); } mcts_backup(M, g, o, 0, X); ++sim; continue; }       // terminal node: value known at once
                 if (f != NO_SLOT && fk == 2) {                                          // its playout has run: the value a fresh playout would return
                     ls.rollouts += 1; ls.rollout_plies += fp; ls.reason_hist4 += 1ull << (4u * (fr & 15u));
-                    ls.spec_hits += 1; ++hits;
+                    ls.spec_hits += 1; ++hits; bias += bias_of(fflags, fv);
                     M.spec_kind[fo] = 0; pool_set(P, f, 0, 0u);
                     mcts_backup(M, g, o, (int)fv, X); ++sim;
                     continue;
@@ -892,9 +903,29 @@ struct Ops {
                 if (want > w + 1) want = w + 1;
             } else if (rounds_left == 0 && want > w + 1) want = w + 1;
             if (want > M.spec_k) want = M.spec_k;
+            if (want > n_sims - sim) want = n_sims - sim;        // (never more playouts than simulations are left)
             uint32_t keep = 1u << pend_slot, ncls = 1;
             const uint32_t issued0 = ls.spec_issued;
-            if (want > 1 && sim + 1 < n_sims && lm.cap > 0) mcts_speculate(M, g, L, sim, want, c_puct, n_sims, C, ls, X, lm, P, keep, ncls);
+            uint32_t req = 1;                                    // playouts requested for this round so far (the pending leaf's)
+            if (want > 1 && sim + 1 < n_sims && lm.cap > 0) {
+                // Scenarios for the pending playout's value: "no decision" (0: ply cap or draw) and "the side that has won more of this
+                // search's playouts wins".  "No decision" goes first (its requests get the better classes) unless three quarters of the
+                // search's playouts were decided: it also predicts right whenever a decision does not change the next selection, which is
+                // the rule in a wide tree (measured at 65 536 games, S = 64: mid-game Copenhagen positions, 55 % decided, 89.9 M sims/s with
+                // 0 first, 79 M with the decisive value first; Brandubh, nearly always decided, 112 M against 123 M).
+                // The second pass may request up to kMctsExtraReq playouts beyond the round's share; what both passes ask for is requested
+                // once (the slot table knows it).
+                const uint32_t dw = bias & 0xFFFFu, aw = bias >> 16;
+                const uint32_t lf = reinterpret_cast<const uint32_t*>(M.spec_state + ((size_t)pend_slot * M.G + g) * IO::QUADS)[IO::WORDS - 1];
+                const double dec = (((lf & TAFL_F_SIDE) != 0u) == (dw >= aw)) ? 1.0 : -1.0;        // seen from the leaf's mover
+                const bool dec_first = scen >= 2u && 4u * (dw + aw) > 3u * sim;
+                mcts_speculate(M, g, L, sim, want, c_puct, n_sims, C, ls, X, lm, P, keep, ncls, req, dec_first ? dec : 0.0);
+                if (scen >= 2u) {
+                    root_load(M, g, X); X.rc.pos_valid = false;
+                    uint32_t w2 = req + kMctsExtraReq; if (w2 > M.spec_k) w2 = M.spec_k;
+                    mcts_speculate(M, g, L, sim, w2, c_puct, n_sims, C, ls, X, lm, P, keep, ncls, req, dec_first ? 0.0 : dec);
+                }
+            }
             M.spec_pend[g] = pend_slot | ((ls.spec_issued - issued0) << 8) | (w_own << 16);
             // requested playouts the pass did not come by (left over from a round that was full) run last
             TAFL_UNROLL for (uint32_t j = 0; j < kMctsMaxSlots; ++j)
@@ -902,9 +933,16 @@ struct Ops {
         } else {
             for (uint32_t j = 0; j < M.spec_k; ++j) M.spec_kind[(size_t)j * M.G + g] = 0;      // the search is over: what is left in the slots is not needed
         }
-        M.sim_next[g] = sim; M.node_top[g] = X.node_top; M.edge_top[g] = X.edge_top;
+        M.sim_next[g] = sim; M.node_top[g] = X.node_top; M.edge_top[g] = X.edge_top; M.spec_bias[g] = bias;
         M.leaf[g] = pend_leaf; M.kind[g] = pending ? 1 : 0;
     }
+
+    // Scenario passes of a step's prediction (a policy: it steers which playouts run when, never a result).  Inside the plan of a short
+    // search the device is full and the rounds are counted: one pass (a second one costs the tree phase 10 % and gains nothing there:
+    // 88 - 90 M sims/s against 95.7 M at S = 64).  A long search (deep trees: the next selection depends on the pending value) takes two
+    // (S = 256: 91.6 -> 94.7 M, S = 1000: 67.5 -> 71 M), and so does every step past the plan or without one (S = 64: 95.7 -> 97.2 M;
+    // a third scenario, "the other side wins", was measured too: more playouts, no fewer rounds).
+    static TAFL_HD uint32_t mcts_scenarios(uint32_t rounds_left, uint32_t planned) { return (rounds_left > 1u && planned < 32u) ? 1u : 2u; }
 
     // playout of slot j of game g (predict() of mcts.py:85 in random-rollout mode), keyed by the leaf's position
     static TAFL_HD void mcts_slot_rollout(const MctsMem& M, uint32_t j, uint32_t g, uint64_t seed, uint64_t game_id, uint32_t sim_offset,

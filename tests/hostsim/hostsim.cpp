@@ -14,6 +14,7 @@
 using namespace tafl;
 
 static uint32_t g_spec_k = 4;          // playout slots per game that exist in the MCTS pipeline (1 = no speculation)
+static uint32_t g_scen = 0;            // scenario passes of the prediction (0: the product's policy, Ops::mcts_scenarios)
 static uint32_t g_spec_target = 0;     // slots per game and round the search is planned for (0: no plan, issue what is allowed)
 static uint32_t g_capacity = 0;        // playouts a round may run (0: all that are requested), like the device capacity of k_mcts_rollout
 static uint32_t g_log_cap = 16;        // undo records of each kind a prediction pass may write (the device's LDS holds 16 per lane; an overflow ends the pass early)
@@ -98,7 +99,7 @@ struct Host {
         M.leaf = leaf.data(); M.kind = kind.data(); M.fault = fault.data();
         M.sim_next = simn.data(); M.spec_state = sst.data(); M.spec_value = sval.data(); M.spec_kind = skind.data(); M.spec_reason = sreason.data(); M.spec_meta = smeta.data();
         M.spec_plies = splies.data(); M.spec_ref = sref.data(); M.spec_cls = scls.data(); M.spec_pend = spend.data();
-        std::vector<uint32_t> simbase(G); M.sim_base = simbase.data();
+        std::vector<uint32_t> simbase(G), sbias(G); M.sim_base = simbase.data(); M.spec_bias = sbias.data();
         memset(stats, 0, sizeof *stats);
         for (uint32_t g = 0; g < G; ++g) { S s; load(st[g], s); O::mcts_init_game(M, g, s, C); }
         // self-play: the batch as the device holds it (quad-plane SoA in the reference layout), per-game counters, the plays
@@ -123,7 +124,7 @@ struct Host {
                     rounds_left = g_spec_target ? (rel < planned_sp ? planned_sp - rel : 1u) : 0u;
                     if (!(simn[g] < p->n_sims || kind[g] == 1)) continue;
                 }
-                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, rounds_left, g_spec_target, g_spec_k, C, ls, lm);
+                O::mcts_tree_step(M, g, p->c_puct, p->n_sims, rounds_left, g_scen ? g_scen : O::mcts_scenarios(rounds_left, planned_sp), g_spec_k, C, ls, lm);
                 stats->sims += ls.sims; stats->tree_depth_sum += ls.depth; stats->children_scanned += ls.scanned;
                 stats->terminal_hits += ls.terminal_hits; stats->faults += ls.faults;
                 stats->rollouts += ls.rollouts; stats->rollout_plies += ls.rollout_plies;
@@ -254,6 +255,7 @@ int hs_selfplay(const tafl_rules* r, uint8_t n, uint32_t word_bits, tafl_state* 
 }
 void hs_set_spec_k(uint32_t k) { g_spec_k = k < 1 ? 1 : (k > 8 ? 8 : k); }
 void hs_set_spec_target(uint32_t t) { g_spec_target = t > 8 ? 8 : t; }
+void hs_set_scenarios(uint32_t s) { g_scen = s > 2 ? 2 : s; }
 void hs_set_capacity(uint32_t c) { g_capacity = c; }
 void hs_set_log_cap(uint32_t c) { g_log_cap = c; }
 uint32_t hs_round_work(uint32_t* out, uint32_t cap) { const uint32_t n = (uint32_t)g_round_work.size(); for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = g_round_work[i]; return n; }

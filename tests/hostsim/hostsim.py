@@ -45,6 +45,8 @@ def lib():
         L.hs_gmcts_root_children.argtypes = [vp, P(TaflRootChild), u32, P(u32)]
         L.hs_gmcts_counts.restype = None
         L.hs_gmcts_counts.argtypes = [vp, P(u64)]
+        L.hs_set_scenarios.restype = None
+        L.hs_set_scenarios.argtypes = [C.c_uint32]
         L.hs_set_spec_target.restype = None
         L.hs_set_spec_target.argtypes = [C.c_uint32]
         L.hs_set_dense13.restype = None
@@ -144,6 +146,11 @@ def set_spec_k(k: int, target: int = 0, capacity: int = 0):
     lib().hs_set_spec_k(k)
     lib().hs_set_spec_target(target)
     lib().hs_set_capacity(capacity)
+
+
+def set_scenarios(s: int):
+    """Scenario passes of every prediction (1 or 2); 0 = the product's policy (Ops::mcts_scenarios)."""
+    lib().hs_set_scenarios(s)
 
 
 def round_work():

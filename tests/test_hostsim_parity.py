@@ -247,6 +247,38 @@ def test_mcts_with_a_full_device_round_capacity(k, target, capacity):
     assert list(ostats.reason_hist) == list(hstats.reason_hist)
 
 
+@pytest.mark.parametrize("scen", [1, 2])
+@pytest.mark.parametrize("name,sims,capacity", [("brandubh7", 90, 0), ("copenhagen11", 70, 0), ("brandubh7", 60, 50), ("copenhagen13", 24, 0)])
+def test_mcts_prediction_scenarios_do_not_change_results(name, sims, capacity, scen):
+    """The prediction pass runs one or two scenarios for the pending playout's value (no decision / the side that has won more of
+    the search's playouts wins): which, in which order and how many is a policy (Ops::mcts_scenarios).  Whatever it is, the search
+    equals the sequential one bit for bit - positions at several phases of a game, with and without a full device."""
+    from tests.hostsim import hostsim
+    rules, fen, wb = pu.CONFIGS[name]
+    n, G = abi.fen_side_len(fen), 12
+    lg, hs = orc.GameLogic(rules, n), HostSim(rules, n, wb)
+    states = pu.start_states(orc, fen, rules.starting_side, wb, G)
+    plies = (C.c_uint32 * G)(*[(i * 11) % 60 for i in range(G)])
+    orc.batch_random_advance(lg, states, G, wb, 31, plies, 4)
+    p = TaflMctsParams(sims, 96, 1.0, 8, 0, 0)
+    ok, on, ostats = orc.batch_mcts(lg, states, G, wb, p, 4)
+    hostsim.set_spec_k(8, 4, capacity)
+    hostsim.set_scenarios(scen)
+    try:
+        hk, hn, hstats = hs.mcts(states, G, p, 4)
+    finally:
+        hostsim.set_spec_k(4, 0, 0)
+        hostsim.set_scenarios(0)
+    assert list(on) == list(hn)
+    for g in range(G):
+        for j in range(on[g]):
+            a, b = ok[g * 256 + j], hk[g * 256 + j]
+            assert (a.action, a.visits, float(a.q).hex()) == (b.action, b.visits, float(b.q).hex()), (g, j)
+    for f in ("sims", "rollouts", "rollout_plies", "tree_depth_sum", "children_scanned", "terminal_hits", "faults"):
+        assert getattr(ostats, f) == getattr(hstats, f), f
+    assert list(ostats.reason_hist) == list(hstats.reason_hist)
+
+
 @pytest.mark.parametrize("name,sims,k", [("brandubh7", 150, 4), ("copenhagen11", 140, 8), ("tablut9", 120, 1)])
 def test_mcts_first_play_urgency_flag(name, sims, k):
     """TAFL_MCTS_FLAG_FPU_INF (the src/mcts.rs sketch: unvisited actions score +inf, mcts.rs:49-51; a new node starts with visits 1,

@@ -1,0 +1,11 @@
+set -e
+cp alphazeroforhnefatafl_amd/libtaflhip.so /tmp/lib_orig.so
+for v in w1 w2 w3 w4; do
+  cp variants/lib_$v.so alphazeroforhnefatafl_amd/libtaflhip.so
+  echo "== $v" >> gpurun_out/var.log
+  python tools/mcts_rounds.py >> gpurun_out/var.log 2>&1
+  python bench.py --no-cpu-baseline > gpurun_out/var_$v.json 2> gpurun_out/var_$v.err
+  python -c "
+import json; d=json.load(open('gpurun_out/var_$v.json')); print('$v', d['digest'][:420]); print('   executed', d['roofline']['playouts_executed'])" | tee -a gpurun_out/var.log
+done
+cp /tmp/lib_orig.so alphazeroforhnefatafl_amd/libtaflhip.so
