@@ -1,3 +1,6 @@
+# A/B harness for policy variants of the library on ONE GPU box (gpurun -- 'bash tools/variants_run.sh'): variants/lib_<name>.so are
+# builds of csrc/ with different -D switches (variants/ is git-ignored but travels to the box); each is put in the library's place,
+# runs tools/mcts_rounds.py (round trace) and the default bench line, and the original library is restored.  Edit the list below.
 set -e
 cp alphazeroforhnefatafl_amd/libtaflhip.so /tmp/lib_orig.so
 for v in w1 w2 w3 w4; do
