@@ -738,7 +738,7 @@ struct Ops {
                 uint32_t f = pool_find(P, ref);
                 const bool known = f != NO_SLOT;
                 const uint8_t fk = pool_kind(P, f);
-                bool ok = true;
+                bool ok = h.m < ORD_SELF;                         // (the ordinal must fit the slot reference)
                 if ((!known || (fk == 1 && !((keep >> f) & 1u))) && req >= want) ok = false;      // this round's share of playouts is used up
                 if (ok && !known) { f = pool_alloc(P, keep); ok = f != NO_SLOT; }
                 const size_t so = (size_t)(ok ? f : 0u) * M.G + g;
@@ -843,7 +843,7 @@ struct Ops {
                 uint32_t f = NO_SLOT; uint8_t fk = 0, fr = 0; int8_t fv = 0; uint32_t fp = 0, fflags = 0;
                 if (o.kind == 4) {
                     // a slot holds exactly this child (same node, same ordinal): state, play and legal-play count are there, no canon_next / apply
-                    f = pool_find(P, slot_ref(o.parent, o.pslot));
+                    f = o.pslot < ORD_SELF ? pool_find(P, slot_ref(o.parent, o.pslot)) : NO_SLOT;       // (an ordinal beyond the reference's 12 bits: no slot ever holds it)
                     if (f == NO_SLOT) { deferred = true; break; }
                     fk = pool_kind(P, f);
                     const size_t so = (size_t)f * M.G + g;

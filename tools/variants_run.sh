@@ -3,7 +3,7 @@
 # runs tools/mcts_rounds.py (round trace) and the default bench line, and the original library is restored.  Edit the list below.
 set -e
 cp alphazeroforhnefatafl_amd/libtaflhip.so /tmp/lib_orig.so
-for v in w1 w2 w3 w4; do
+for v in p0 p1 p2; do
   cp variants/lib_$v.so alphazeroforhnefatafl_amd/libtaflhip.so
   echo "== $v" >> gpurun_out/var.log
   python tools/mcts_rounds.py >> gpurun_out/var.log 2>&1
