@@ -46,7 +46,7 @@ extern "C" int tafl_prof_read(unsigned long long* out, int reset) {
 #ifndef TAFL_ROLLOUT_WAVES
 #define TAFL_ROLLOUT_WAVES 2
 #endif
-#define TAFL_MCTS_MAX_SLOTS 8        /* playout slots per game (slot 0 + up to 7 predicted simulations) */
+#define TAFL_MCTS_MAX_SLOTS 8        /* playout slots per game (the pending leaf + up to 7 predicted ones) */
 static_assert(TAFL_MCTS_MAX_SLOTS == tafl::kMctsMaxSlots, "slot bound of tafl_ops.hpp");
 #define TAFL_MCTS_MAX_PARTS 8         /* partitions of a batch that run the two-kernel pipeline on their own streams */
 #define TAFL_MCTS_TRACE_ROUNDS 4096   /* rounds of a search whose work counts are kept for tafl_mcts_round_trace */
@@ -1308,7 +1308,7 @@ static int mcts_begin(tafl_batch* b, const tafl_mcts_params* p, uint64_t game_id
             P.wc = wcount + (size_t)k * 2 * TAFL_MCTS_MAX_SLOTS;              // two counter sets per partition: the playout launch of a round clears the next round's
         }
     }
-    // every round runs min(capacity, requested) playouts, slot 0 of every waiting game first: progress is guaranteed
+    // every round runs min(capacity, requested) playouts, the pending leaf of every waiting game first (class 0): progress is guaranteed
     // a large batch always has stragglers that need a few rounds more than the plan (65 536 games: 5 - 6)
     const uint32_t tail_guess = n >= 32768u ? 6u : n >= 4096u ? 4u : n >= 512u ? 2u : 1u;
     const unsigned long long rounds_bound = ((unsigned long long)p->n_sims + 2 + tail_guess) * (1 + (unsigned long long)n / (capacity ? capacity : 1));

@@ -213,8 +213,8 @@ typedef struct tafl_mcts_params {
  * (tests/test_gpu_parity.py::test_mcts_pipelines_agree).
  *   bits 4-7   pipeline: 0 default (64-bit boards: fused; wider boards: two kernels per round, tree phase + playouts over dense work
  *              lists), 1 fused (one kernel per chunk of rounds, at most 2 playout slots per game; 64-bit boards only), 2 two-kernel
- *   bits 8-11  playout slots per game in flight (slot 0 = the pending simulation, the rest are predicted simulations, DESIGN.md
- *              section 6); 0 = chosen from the batch size, at most 8
+ *   bits 8-11  playout slots per game (one holds the pending simulation's leaf, the rest predicted leaves, DESIGN.md
+ *              section 4.5); 0 = chosen from the batch size, at most 8
  *   bits 12-15 partitions of the batch that run the pipeline on their own streams (two-kernel pipeline); 0 = from the batch size, at most 8 */
 #define TAFL_MCTS_PIPELINE_DEFAULT 0u
 #define TAFL_MCTS_PIPELINE_FUSED 1u

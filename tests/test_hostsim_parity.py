@@ -220,7 +220,7 @@ def test_mcts_speculative_slots_do_not_change_results(k, cooldown):
 @pytest.mark.parametrize("k,target,capacity", [(8, 4, 70), (8, 0, 40), (4, 4, 33), (8, 8, 1), (2, 2, 20)])
 def test_mcts_with_a_full_device_round_capacity(k, target, capacity):
     """More playouts requested than one round may run (the device holds occupancy x CUs x 64 lanes at once): the rest waits for the
-    next round, slot 0 of every waiting game first.  Same results as the sequential search, bit for bit."""
+    next round, the pending leaf of every waiting game first.  Same results as the sequential search, bit for bit."""
     from tests.hostsim import hostsim
     rules, fen, wb = pu.CONFIGS["brandubh7"]
     n, G = 7, 32
