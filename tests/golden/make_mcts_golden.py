@@ -6,8 +6,10 @@ the output is data — inputs and expected root statistics).  The reference `MCT
 (src/mcts.py:11-136) is driven through the alpha-zero-general duck-typed `game`/`nnet`
 protocol it expects (src/mcts.py:40-41,75,78,85-86,122-123) by a thin adaptor whose game
 methods call OUR CPU oracle and whose `predict` returns an all-ones prior plus the value of one
-seeded random playout (SURVEY.md §8a resolution, DESIGN.md "MCTS semantics").  States are keyed
-by their move path, so no transpositions merge (the tree is explicit, as in src/mcts.rs).
+seeded random playout (SURVEY.md §8a resolution, DESIGN.md "MCTS semantics"); the playout's RNG
+stream is a function of (seed, game id, position) - `logic.state_hash`, include/taflhip.h "leaf
+key" - as a network's predict is a function of the board.  States are keyed by their move path,
+so no transpositions merge (the tree is explicit, as in src/mcts.rs).
 
 Usage:  python tests/golden/make_mcts_golden.py
 """
